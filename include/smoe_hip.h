@@ -1,0 +1,165 @@
+/*
+ * smoe_hip.h -- C ABI of libsmoe_hip.so: the MI355X (gfx950) implementation of the
+ * per-block Steered-Mixture-of-Experts fit / reconstruction hot path.
+ *
+ * The reference (roljon/Steered-Mixture-of-Experts, /root/reference) has no FFI or
+ * plugin interface: its only seam is Python -> tf.Session.run().  Each entry point
+ * below replaces one group of session.run() calls of the reference; the reference
+ * lines are cited per function.  A maintainer binds these with ctypes (see
+ * INTEGRATION.md); the signatures carry plain pointers and sizes only.
+ *
+ * Semantics: every image block is an independent model ("one Smoe instance per
+ * block"): own [0,1]^d pixel domain, own K kernels, own Adam state.  B blocks are
+ * processed by one launch.
+ *
+ * Memory: every array argument is CALLER-OWNED DEVICE memory (hipMalloc'd or a
+ * torch tensor's data_ptr()) on the handle's device unless it says "host".  The
+ * library allocates only a small workspace inside the handle.  Calls are
+ * asynchronous on the hipStream_t passed as `stream` (NULL = default stream).
+ *
+ * Errors: every call returns SMOE_OK (0) or a negative smoe_status; no exceptions,
+ * no aborts.  smoe_last_error() returns a thread-local message for the last failure.
+ *
+ * Threading: a handle is bound to one device and is not thread-safe; use one handle
+ * per device (one process per GPU).  No global state besides the error string.
+ */
+#ifndef SMOE_HIP_H
+#define SMOE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMOE_ABI_VERSION 1
+#define SMOE_MAX_DIM 3
+#define SMOE_MAX_CHANNELS 3
+
+typedef enum smoe_status {
+    SMOE_OK = 0,
+    SMOE_ERR_INVALID = -1,      /* bad argument / shape                                  */
+    SMOE_ERR_UNSUPPORTED = -2,  /* (dim, channels, kernels) combination not instantiated */
+    SMOE_ERR_HIP = -3,          /* a HIP runtime call failed                             */
+    SMOE_ERR_NO_DEVICE = -4     /* no usable gfx950 device                               */
+} smoe_status;
+
+/* Hyper-parameters of the model + optimiser.  Defaults a caller should use are the
+ * smoe_test.py CLI defaults (smoe_test.py:262-352) with kernel adding off. */
+typedef struct smoe_config {
+    int32_t abi_version;        /* = SMOE_ABI_VERSION                                                    */
+    int32_t device;             /* HIP device ordinal                                                    */
+    int32_t dim;                /* d: 2 (image) or 3 (video)              smoe.py:227                   */
+    int32_t block_shape[SMOE_MAX_DIM]; /* pixels per block per axis (y, x[, t]); unused axes = 1  smoe.py:231-245 */
+    int32_t channels;           /* C                                      smoe.py:542                   */
+    int32_t kernels;            /* K kernels per block                    smoe.py:2156-2161             */
+    int32_t precision;          /* bits of the pixel lattice (8)          utils.py:126-131              */
+    float   margin;             /* epsilon = margin / 2^precision         smoe.py:931                   */
+    int32_t use_determinant;    /* Gaussian normalisation by prod diag(A) smoe.py:809-815               */
+    int32_t use_yuv;            /* 6/8,1/8,1/8 channel loss weights       smoe.py:933-935               */
+    int32_t train_pis;          /* trainable flags                        smoe.py:389-396               */
+    int32_t train_gammas;
+    int32_t train_musx;
+    float   lr_expert;          /* optimizer1 {nu_e, gamma_e, musX}       smoe_test.py:84, smoe.py:1102 */
+    float   lr_pis;             /* optimizer2 {pis}                       smoe_test.py:85, smoe.py:1103 */
+    float   lr_steer;           /* optimizer3 {A_diagonal, A_corr}        smoe_test.py:86, smoe.py:1104 */
+    float   beta1, beta2, adam_eps;   /* tf.train.AdamOptimizer defaults .9/.999/1e-8                    */
+    float   grad_clip;          /* clip(grad, +-v) if > 0                 smoe.py:1152-1153             */
+    float   pis_l1;             /* pis_l1 * sum(pis) / start_pis          smoe.py:1027                  */
+    float   u_l1;               /* u_l1 * sum(diag A)                     smoe.py:1044                  */
+    int32_t start_pis;          /* normaliser K0 of the l1 term           smoe.py:264,1025              */
+} smoe_config;
+
+/* Parameter set in the reference's get_params() layout (smoe.py:1795-1800) with a
+ * leading block axis B, fp32, C-contiguous:
+ *   pis[B,K]  musX[B,K,d]  A_diagonal[B,K,d,d]  A_corr[B,K,d,d]  gamma_e[B,K,d,C]  nu_e[B,K,C]
+ * Only the diagonal of A_diagonal and the strict lower triangle of A_corr are read or
+ * written (smoe.py:732-733); the other entries are carried untouched. */
+typedef struct smoe_params {
+    float* pis;
+    float* musX;
+    float* A_diagonal;
+    float* A_corr;
+    float* gamma_e;
+    float* nu_e;
+} smoe_params;
+
+/* TF1 Adam slots (m, v per variable, same layout as smoe_params) and the running
+ * beta powers, which TF keeps per optimizer and multiplies after every apply. */
+typedef struct smoe_adam_state {
+    smoe_params m;
+    smoe_params v;
+    float   beta1_power;        /* host, in/out; initialise to beta1 */
+    float   beta2_power;        /* host, in/out; initialise to beta2 */
+    int64_t step;               /* host, in/out; number of applied steps */
+} smoe_adam_state;
+
+typedef struct smoe_context* smoe_handle;
+
+/* Create / destroy a handle.  Replaces Smoe.__init__ -> init_model graph construction
+ * (smoe.py:229,313,331-1064): builds the per-block pixel domain linspace(0,1,size) per
+ * axis (gen_domain, smoe.py:2395-2426) on the device. */
+int smoe_create(smoe_handle* out, const smoe_config* cfg);
+int smoe_destroy(smoe_handle h);
+
+/* 1 if the (dim, channels, kernels) combination has a compiled kernel. */
+int smoe_is_supported(int32_t dim, int32_t channels, int32_t kernels);
+
+/* Copy the device-resident per-pixel coordinates [d][N] (fp32) to a HOST buffer. */
+int smoe_get_coords(smoe_handle h, float* host_out);
+
+/* Evaluation pass.  Replaces run_batched(train=False, update_reconstruction=True)
+ * (smoe.py:1606-1793; fetches at 1646-1648,1686-1697): for every block computes the
+ * gate, the reconstruction and the loss with the block's current active-kernel mask,
+ * then replaces the mask by the kernels that have influence (smoe.py:829-836,1763-1766).
+ *   target  [B,C,N] fp32 in [0,1] (channel-planar per block)      loss_w [B,N] or NULL (smoe.py:550)
+ *   recon   [B,C,N] or NULL  (quantised reconstruction, smoe.py:857,899)
+ *   argmax  [B,N] uint8 or NULL (smoe.py:833 mapped to kernel ids as at smoe.py:1706-1716)
+ *   gate_w  [B,K,N] or NULL  (masked gate, smoe.py:837, zero rows for pruned kernels)
+ *   loss    [B]  loss_op (smoe.py:1051)      sse [B]  sum of squared error (mse_op = sse/(N*C)*(2^p)^2, smoe.py:1053)
+ *   active  [B] uint32 bit k = kernel k in kernel_list, in/out; update_active=0 leaves it unchanged */
+int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const float* loss_w,
+                 const smoe_params* p, float* recon, uint8_t* argmax, float* gate_w,
+                 float* loss, float* sse, uint32_t* active, int32_t update_active, void* stream);
+
+/* n_iters training iterations.  Replaces the loop body of Smoe.train (smoe.py:1521-1529):
+ * run_batched(train=True) = zero accumulators (1613), forward + tf.gradients (1702,1148),
+ * kernel-list prune (1763-1766), one ApplyAdam per group (1788,1173-1193), and the
+ * per-iteration divergence test (1565-1570, per block).
+ *   p, s      in/out           loss_last/sse_last [B]: values of the LAST train pass (may be NULL)
+ *   active    [B] in/out       diverged [B] uint32 in/out (non-zero = block frozen), may be NULL
+ *   loss0     [B] iteration-0 loss for the blow-up test, or NULL (NaN test only) */
+int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float* loss_w,
+             smoe_params* p, smoe_adam_state* s, int32_t n_iters,
+             float* loss_last, float* sse_last, uint32_t* active, uint32_t* diverged,
+             const float* loss0, void* stream);
+
+/* Kernel re-admission.  Replaces update_kernel_list (smoe.py:2287-2365) for a per-block
+ * [0,1]^d domain: active |= (pis > 0) & any_probe(maha < 800), probes = {min,max,mid}^d. */
+int smoe_update_kernel_list(smoe_handle h, int32_t num_blocks, const smoe_params* p,
+                            uint32_t* active, void* stream);
+
+/* Best snapshot.  Replaces checkpoint_best_op (smoe.py:861-896, trigger 1574-1576), per
+ * block: where loss[b] < best_loss[b] copy p -> best and loss -> best_loss. */
+int smoe_checkpoint_best(smoe_handle h, int32_t num_blocks, const float* loss, float* best_loss,
+                         const smoe_params* p, smoe_params* best, void* stream);
+
+/* Block -> scalars.  Replaces the host accumulation of smoe.py:1758-1759,1761:
+ * out_dev[0] = sum_b loss[b]*N, out_dev[1] = sum_b sse[b], out_dev[2] = sum_b popcount(active[b]).
+ * out_dev: 3 doubles in DEVICE memory (ready for an RCCL all-reduce by the host layer). */
+int smoe_reduce_scalars(smoe_handle h, int32_t num_blocks, const float* loss, const float* sse,
+                        const uint32_t* active, double* out_dev, void* stream);
+
+/* Name of the kernel variant smoe_fit would launch for num_blocks (diagnostics / profiles). */
+const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks);
+
+/* Force the lanes-per-block tiling (16, 64; 0 = automatic).  Tuning / test hook. */
+int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
+
+const char* smoe_last_error(void);
+int smoe_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOE_HIP_H */

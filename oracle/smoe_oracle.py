@@ -1,0 +1,464 @@
+"""CPU restatement (numpy) of the reference's per-block SMoE hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package
+``steered_mixture_of_experts_amd``) may import this module; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do, and only
+as the checker / the timed CPU baseline.
+
+PARITY UNPINNED.  The reference (roljon/Steered-Mixture-of-Experts) ships no
+tests, fixtures or golden vectors, and its arithmetic lives in TensorFlow 1.x
+(version unpinned, not vendored, not installable here), so this restatement
+cannot be checked against outputs of the reference itself.  It is written from
+the reference's source text, function by function (citations below are
+``file:line`` under ``/root/reference``), and is cross-checked by
+``tests/test_oracle.py`` against (i) ``torch.autograd`` on an independent
+forward, (ii) central finite differences, (iii) hand known-answer cases that
+follow from the reference's initialisers, and (iv) the plain-C restatement in
+``oracle/smoe_oracle.c``.
+
+Semantics: every image block is an independent ``Smoe`` instance (own [0,1]^d
+domain, own K kernels, own Adam state); all arrays carry a leading block axis
+``B``.  ``dtype`` selects fp64 (master) or fp32 (what TF computes in).
+
+Third-party arithmetic restated here (TensorFlow 1.x, call sites in smoe.py):
+  * ``tf.train.AdamOptimizer`` / ``ApplyAdam``:
+        alpha = lr*sqrt(1-beta2^t)/(1-beta1^t); m += (g-m)(1-beta1);
+        v += (g*g-v)(1-beta2); var -= m*alpha/(sqrt(v)+eps)
+    with beta^t kept as a running fp32 product (smoe_test.py:84-88,
+    smoe.py:1173-1193).
+  * ``tf.quantization.fake_quant_with_min_max_args(x, 0, 1, num_bits=p)``
+    (smoe.py:899): scale = 1/(2^p-1), zero point 0, nudged range [0, (2^p-1)*scale],
+    out = floor(clamp(x)*inv_scale + 0.5)*scale, gradient 1 inside the range.
+  * ``tf.clip_by_value`` (smoe.py:857): gradient 1 on [0,1] inclusive.
+  * ``tf.maximum(10e-12, s)`` (smoe.py:821): gradient to ``s`` iff s > 1e-11.
+"""
+from __future__ import annotations
+
+import dataclasses
+import itertools
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+PARAM_NAMES = ("pis", "musX", "A_diagonal", "A_corr", "gamma_e", "nu_e")
+
+
+@dataclasses.dataclass
+class OracleConfig:
+    """Hyper-parameters of one fit; defaults = smoe_test.py CLI defaults with
+    kernel adding off."""
+    block_shape: Tuple[int, ...]          # (bh, bw) or (bh, bw, bt)
+    channels: int
+    kernels: int
+    precision: int = 8                    # utils.py:126-131
+    margin: float = 0.5                   # smoe.py:41
+    use_determinant: bool = True          # smoe_test.py:293-294
+    use_yuv: bool = False                 # smoe_test.py:41-44 (forced False unless C==3)
+    train_pis: bool = True
+    train_gammas: bool = True
+    train_musx: bool = True
+    lr_expert: float = 1e-3               # optimizer1 {nu_e, gamma_e, musX}  smoe_test.py:84
+    lr_pis: float = 1e-5                  # optimizer2 {pis}                  smoe_test.py:85
+    lr_steer: float = 1.0                 # optimizer3 {A_diagonal, A_corr}   smoe_test.py:86
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1e-8
+    grad_clip: Optional[float] = None     # smoe.py:1152-1153
+    pis_l1: float = 0.0                   # smoe.py:1027
+    u_l1: float = 0.0                     # smoe.py:1044
+    start_pis: Optional[int] = None       # smoe.py:264 (K0 of the l1 normaliser)
+
+    @property
+    def dim(self) -> int:
+        return len(self.block_shape)
+
+    @property
+    def pixels(self) -> int:
+        return int(np.prod(self.block_shape))
+
+    @property
+    def k0(self) -> int:
+        return self.kernels if self.start_pis is None else self.start_pis
+
+
+# --------------------------------------------------------------------------
+# domain / initialisers
+# --------------------------------------------------------------------------
+def axis_coords(block_shape: Sequence[int]):
+    """Per-axis pixel coordinates, smoe.py:2412: ``np.linspace(0, 1, size)``."""
+    return [np.linspace(0, 1, int(s)) for s in block_shape]
+
+
+def block_coords(block_shape: Sequence[int], dtype=np.float32) -> np.ndarray:
+    """(N, d) pixel coordinates of one block, 'ij' meshgrid flattened row-major
+    (smoe.py:2418-2421, 1650); fed to TF as float32 (smoe.py:545)."""
+    grids = np.meshgrid(*axis_coords(block_shape), indexing="ij")
+    dom = np.stack(grids, axis=-1).reshape(-1, len(block_shape))
+    return dom.astype(np.float32).astype(dtype)
+
+
+def kernel_grid(kernels_per_dim: Sequence[int], dim: int) -> np.ndarray:
+    """(K, d) kernel centres, smoe.py:2402-2415,2424: equal spacing to the
+    border, ``linspace(1/(2n), 1-1/(2n), n)`` per axis."""
+    kpd = list(kernels_per_dim)
+    if len(kpd) == 1:
+        kpd = kpd * dim
+    coord = [np.linspace((1 / n) / 2, 1 - (1 / n) / 2, n) for n in kpd]
+    grids = np.meshgrid(*coord, indexing="ij")
+    return np.reshape(np.stack(grids, axis=-1), (int(np.prod(kpd)), dim))
+
+
+def init_params(blocks: np.ndarray, kernels_per_dim: Sequence[int],
+                normalize_pis: bool = True, train_inverse_cov: bool = False
+                ) -> Dict[str, np.ndarray]:
+    """Initial parameters of every block, as ``Smoe(block_b, kernels_per_dim)``
+    would build them.  ``blocks``: (B, *block_shape, C) float32 in [0,1].
+
+    smoe.py:2146-2163 (grid, A_init = diag(2*(k_i+1))), 2165-2235 (nu_e = mean
+    of the pixels in the [mu-mu0, mu+mu0) window, Python ``round``),
+    2237-2242 (pis = 1/K), 436-437 (A_corr = 0).  Variables are float32
+    (smoe.py:388-396).
+    """
+    B = blocks.shape[0]
+    shape = blocks.shape[1:-1]
+    C = blocks.shape[-1]
+    d = len(shape)
+    kpd = list(kernels_per_dim)
+    if len(kpd) == 1:
+        kpd = kpd * d
+    mus = kernel_grid(kpd, d)
+    K = mus.shape[0]
+    A_proto = np.diag([2.0 * (k + 1) for k in kpd])
+    if train_inverse_cov:
+        A_proto = A_proto ** 2
+    stride = mus[0]
+    nu = np.empty((B, K, C), dtype=np.float32)
+    for k in range(K):
+        sl = [slice(None)]
+        for ax in range(d):
+            lo = int(round((mus[k, ax] - stride[ax]) * shape[ax]))
+            hi = int(round((mus[k, ax] + stride[ax]) * shape[ax]))
+            sl.append(slice(lo, hi))
+        nu[:, k, :] = np.mean(blocks[tuple(sl)], axis=tuple(range(1, d + 1)))
+    pis = np.ones((K,), dtype=np.float32)
+    if normalize_pis:
+        pis = pis / K
+    out = {
+        "pis": np.tile(pis, (B, 1)),
+        "musX": np.tile(mus.astype(np.float32), (B, 1, 1)),
+        "A_diagonal": np.tile(A_proto.astype(np.float32), (B, K, 1, 1)),
+        "A_corr": np.zeros((B, K, d, d), dtype=np.float32),
+        "gamma_e": np.zeros((B, K, d, C), dtype=np.float32),
+        "nu_e": nu,
+    }
+    return out
+
+
+def zeros_like_params(p: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    return {k: np.zeros_like(v) for k, v in p.items()}
+
+
+def new_adam_state(p: Dict[str, np.ndarray]) -> Dict[str, object]:
+    """TF1 Adam slots: m, v per variable, beta powers start at beta (they are
+    multiplied after each apply)."""
+    return {"m": zeros_like_params(p), "v": zeros_like_params(p), "t": 0,
+            "b1p": None, "b2p": None}
+
+
+# --------------------------------------------------------------------------
+# forward
+# --------------------------------------------------------------------------
+def _steering(p, T):
+    """A = diag(A_diagonal) + strict_lower(A_corr), smoe.py:732-733."""
+    Ad = p["A_diagonal"].astype(T)
+    Ac = p["A_corr"].astype(T)
+    d = Ad.shape[-1]
+    eye = np.eye(d, dtype=bool)
+    low = np.tril(np.ones((d, d), dtype=bool), -1)
+    return np.where(eye, Ad, 0) + np.where(low, Ac, 0)
+
+
+def fake_quant01(y, precision, T):
+    """clip (smoe.py:857) then fake_quant_with_min_max_args(0,1,bits)
+    (smoe.py:899); TF kernel: floor(clamped*inv_scale+0.5)*scale in fp32."""
+    levels = T(2 ** precision - 1)
+    scale = T(1) / levels                       # (max-min)/(quant_max-quant_min)
+    inv_scale = T(1) / scale
+    nudged_max = levels * scale
+    yc = np.minimum(np.maximum(y, T(0)), T(1))  # clip_by_value
+    cl = np.minimum(np.maximum(yc, T(0)), nudged_max)
+    return np.floor(cl * inv_scale + T(0.5)) * scale
+
+
+def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
+            active: np.ndarray, cfg: OracleConfig, loss_w: Optional[np.ndarray] = None,
+            dtype=np.float32, want_grads: bool = False):
+    """One pass of the reference graph over B independent blocks.
+
+    p: parameter dict with leading B.  target: (B, N, C).  coords: (N, d).
+    active: (B, K) bool = kernel_list (smoe.py:552).  loss_w: (B, N) or None.
+    Returns a dict: y (pre-clip), w (gate), wt (masked gate), recon (quantised),
+    loss (B,), sse (B,), mse_op (B,), active_new (B,K), argmax (B,N), num_pi (B,),
+    and when ``want_grads`` the analytic gradients ``grads`` (dict like p).
+    """
+    T = dtype
+    B, N, C = target.shape
+    K = p["pis"].shape[1]
+    d = coords.shape[1]
+    x = coords.astype(T)                                    # (N,d)
+    t = target.astype(T)
+    pis = p["pis"].astype(T)
+    mu = p["musX"].astype(T)
+    nu = p["nu_e"].astype(T)
+    gam = p["gamma_e"].astype(T)
+    A = _steering(p, T)                                      # (B,K,d,d)
+    lw = np.ones((B, N), dtype=T) if loss_w is None else loss_w.astype(T)
+
+    # smoe.py:480,738: bool_mask = kernel_list & (pis > 0)
+    act = np.logical_and(active, pis > 0)                    # (B,K)
+
+    # smoe.py:777-782,796: r = x - mu ; z = A^T r ; maha = |z|^2
+    r = x[None, None, :, :] - mu[:, :, None, :]              # (B,K,N,d)
+    z = np.einsum("bknl,bklm->bknm", r, A)                   # z_m = sum_l r_l A[l,m]
+    maha = np.sum(z * z, axis=-1)                            # (B,K,N)
+    n_exp = np.exp(T(-0.5) * maha)                           # smoe.py:807
+    if cfg.use_determinant:                                  # smoe.py:809-815
+        n_div = np.prod(np.diagonal(A, axis1=-2, axis2=-1), axis=-1)   # (B,K)
+        n_dis = T(np.sqrt(np.power(2 * np.pi, d)))
+        n_quo = n_div / n_dis
+        Nk = n_quo[:, :, None] * n_exp
+    else:
+        n_quo = np.ones((B, K), dtype=T)
+        Nk = n_exp
+    g = Nk * pis[:, :, None]                                 # smoe.py:819
+    g = np.where(act[:, :, None], g, T(0))                   # masked-out kernels are absent
+    S_raw = np.sum(g, axis=1)                                # (B,N)
+    S = np.maximum(T(10e-12), S_raw)                         # smoe.py:821
+    w = g / S[:, None, :]                                    # smoe.py:823
+    tau = T(0.5 * 1 / (2 ** cfg.precision))                  # smoe.py:825
+    M = w > tau                                              # tf.greater: strict
+    wt = np.where(M, w, T(0))                                # smoe.py:827
+
+    active_new = np.any(M, axis=2)                           # smoe.py:829,836
+    # smoe.py:833: argmax over the compacted list, mapped back via indices (1706-1716)
+    wt_for_arg = np.where(active_new[:, :, None], wt, T(-1))
+    argmax = np.argmax(wt_for_arg, axis=1).astype(np.int64)  # first max
+    argmax = np.where(np.any(active_new, axis=1)[:, None], argmax, 0)
+
+    # smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
+    e = nu[:, :, None, :] + np.einsum("bklc,nl->bknc", gam, x)   # (B,K,N,C)
+    if not cfg.train_gammas:
+        e = np.broadcast_to(nu[:, :, None, :], (B, K, N, C)).astype(T)
+    y = np.sum(wt[..., None] * e, axis=1)                    # (B,N,C)
+    q = fake_quant01(y, cfg.precision, T)                    # smoe.py:857,899
+
+    diff = q - t                                             # smoe.py:905
+    sse = np.sum(np.square(diff), axis=(1, 2))               # (B,)
+    mse_op = sse / T(N * C) * T((2 ** cfg.precision) ** 2)   # smoe.py:927,1053
+    eps = T(cfg.margin * 1 / (2 ** cfg.precision))           # smoe.py:931
+    a = np.abs(diff) - eps
+    lp = np.maximum(T(0), np.square(a)) * lw[:, :, None]     # smoe.py:932
+    if cfg.use_yuv:                                          # smoe.py:933-935
+        cw = np.array([6 / 8] + [1 / 8] * (C - 1), dtype=T) / T(N)
+    else:                                                    # smoe.py:937
+        cw = np.full((C,), 1.0 / (N * C), dtype=T)
+    loss_pixel = np.sum(np.sum(lp, axis=1) * cw[None, :], axis=1)
+    diagA = np.diagonal(A, axis1=-2, axis2=-1)               # (B,K,d)
+    reg_pi = T(cfg.pis_l1) * np.sum(np.where(act, pis, T(0)), axis=1) / T(cfg.k0)     # smoe.py:1027
+    reg_u = T(cfg.u_l1) * np.sum(np.where(act[:, :, None], diagA, T(0)), axis=(1, 2))  # smoe.py:1044
+    loss = loss_pixel + reg_pi + reg_u                       # smoe.py:1051
+
+    out = {"y": y, "w": w, "wt": wt, "recon": q, "loss": loss, "sse": sse,
+           "mse_op": mse_op, "active_new": active_new, "argmax": argmax,
+           "num_pi": np.sum(pis > 0, axis=1), "S": S_raw}
+    if not want_grads:
+        return out
+
+    # ---- analytic reverse pass ------------------------
+    inside = np.logical_and(y >= T(0), y <= T(1))            # clip + fake-quant STE
+    G = (cw[None, None, :] * T(2) * a * np.sign(diff) * lw[:, :, None]) * inside   # (B,N,C)
+    # experts
+    g_nu = np.einsum("bkn,bnc->bkc", wt, G)
+    g_gam = np.einsum("bkn,nl,bnc->bklc", wt, x, G)
+    # gate
+    h = np.where(M, np.einsum("bknc,bnc->bkn", e, G), T(0))  # (B,K,N)
+    dotp = np.sum(h * w, axis=1)                             # (B,N)
+    passS = (S_raw > T(10e-12))[:, None, :]                  # tf.maximum tie -> constant
+    u = np.where(passS, w * (h - dotp[:, None, :]), h * w)   # dL/dlog g  (if floored: dL/dg*g = h*g/S)
+    u = np.where(act[:, :, None], u, T(0))
+    safe_pi = np.where(act, pis, T(1))
+    g_pi = np.where(act, np.sum(u, axis=2) / safe_pi + T(cfg.pis_l1) / T(cfg.k0), T(0))
+    # steering: dm/dA[l,m] = 2 r_l z_m, dL/dm = -u/2
+    g_A = -np.einsum("bkn,bknl,bknm->bklm", u, r, z)         # (B,K,d,d), valid for l>=m
+    if cfg.use_determinant:
+        safe_d = np.where(act[:, :, None], diagA, T(1))
+        g_A = g_A + np.einsum("bk,bkl,lm->bklm", np.sum(u, axis=2), T(1) / safe_d,
+                              np.eye(d, dtype=T))
+    g_A = g_A + np.where(act[:, :, None, None], T(cfg.u_l1) * np.eye(d, dtype=T), T(0))
+    eye = np.eye(d, dtype=bool)
+    low = np.tril(np.ones((d, d), dtype=bool), -1)
+    g_Adiag = np.where(eye, g_A, T(0))
+    g_Acorr = np.where(low, g_A, T(0))
+    # centres: dm/dmu = -2 A z
+    Az = np.einsum("bklm,bknm->bknl", A, z)
+    g_mu = np.einsum("bkn,bknl->bkl", u, Az)
+    if not cfg.train_gammas:
+        g_gam = np.zeros_like(g_gam)
+    out["grads"] = {"pis": g_pi, "musX": g_mu, "A_diagonal": g_Adiag, "A_corr": g_Acorr,
+                    "gamma_e": g_gam, "nu_e": g_nu}
+    return out
+
+
+# --------------------------------------------------------------------------
+# optimiser (TF1 Adam, three groups)
+# --------------------------------------------------------------------------
+def adam_step(p, grads, state, cfg: OracleConfig, dtype=np.float32, frozen=None):
+    """One ``session.run(train_op)`` (smoe.py:1788): dense TF1 ApplyAdam on every
+    trainable variable of a group whose lr != 0 (smoe.py:1112-1144,1173-1193).
+    ``frozen``: optional (B,) bool of blocks that must not move (diverged)."""
+    T = dtype
+    b1, b2, eps = T(cfg.beta1), T(cfg.beta2), T(cfg.adam_eps)
+    if state["b1p"] is None:
+        state["b1p"], state["b2p"] = b1, b2
+    b1p, b2p = T(state["b1p"]), T(state["b2p"])
+    groups = {
+        "nu_e": (cfg.lr_expert, True), "gamma_e": (cfg.lr_expert, cfg.train_gammas),
+        "musX": (cfg.lr_expert, cfg.train_musx), "pis": (cfg.lr_pis, cfg.train_pis),
+        "A_diagonal": (cfg.lr_steer, True), "A_corr": (cfg.lr_steer, True),
+    }
+    newp = {}
+    for name in PARAM_NAMES:
+        lr, trainable = groups[name]
+        var = p[name].astype(T)
+        if (not trainable) or lr == 0:
+            newp[name] = var
+            continue
+        gr = grads[name].astype(T)
+        if cfg.grad_clip is not None:
+            gr = np.clip(gr, T(-cfg.grad_clip), T(cfg.grad_clip))
+        m = state["m"][name].astype(T)
+        v = state["v"][name].astype(T)
+        alpha = T(lr) * np.sqrt(T(1) - b2p) / (T(1) - b1p)
+        m_new = m + (gr - m) * (T(1) - b1)
+        v_new = v + (gr * gr - v) * (T(1) - b2)
+        var_new = var - (m_new * alpha) / (np.sqrt(v_new) + eps)
+        if frozen is not None:
+            fz = frozen.reshape((-1,) + (1,) * (var.ndim - 1))
+            m_new = np.where(fz, m, m_new)
+            v_new = np.where(fz, v, v_new)
+            var_new = np.where(fz, var, var_new)
+        state["m"][name] = m_new
+        state["v"][name] = v_new
+        newp[name] = var_new
+    state["b1p"] = T(b1p * b1)
+    state["b2p"] = T(b2p * b2)
+    state["t"] += 1
+    return newp
+
+
+# --------------------------------------------------------------------------
+# pass / iteration semantics
+# --------------------------------------------------------------------------
+def readmit(p, active, cfg: OracleConfig, dtype=np.float32):
+    """``update_kernel_list`` (smoe.py:2287-2365) for a per-block [0,1]^d domain:
+    active |= (pis>0) & any_probe(maha < 800), probes = {min, max, mid}^d of the
+    block's coordinates (smoe.py:2322-2333,2350; test at smoe.py:806)."""
+    T = dtype
+    d = cfg.dim
+    axes = axis_coords(cfg.block_shape)
+    tt = [(ax.min(), ax.max(), (ax.min() + ax.max()) / 2) for ax in axes]
+    probes = np.array(list(itertools.product(*tt))).astype(np.float32).astype(T)   # (3^d, d)
+    A = _steering(p, T)
+    mu = p["musX"].astype(T)
+    r = probes[None, None, :, :] - mu[:, :, None, :]
+    z = np.einsum("bknl,bklm->bknm", r, A)
+    maha = np.sum(z * z, axis=-1)
+    near = np.any(maha < T(800), axis=2)
+    return np.logical_or(active, np.logical_and(near, p["pis"] > 0))
+
+
+def fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int = 100,
+        ukl_iter: Optional[int] = None, loss_w=None, dtype=np.float32,
+        record_every: int = 0):
+    """``Smoe.train`` (smoe.py:1485-1603) over B independent blocks.
+
+    Iteration 0: eval pass (prunes ``active`` to the kernels with influence,
+    smoe.py:1763-1766).  Each iteration: train pass with the current ``active``,
+    ``active <- active'``, Adam.  Every ``ukl_iter``: readmit.  Every
+    ``val_iter``: eval pass, per-block best snapshot if the loss improved
+    (smoe.py:1574-1576).  Per-block stop on NaN / blow-up (smoe.py:1565-1570).
+    Returns (params, state, info).
+    """
+    T = dtype
+    if ukl_iter is None:
+        ukl_iter = val_iter
+    B = target.shape[0]
+    K = p["pis"].shape[1]
+    p = {k: v.astype(T) for k, v in p.items()}
+    state = new_adam_state(p)
+    active = np.ones((B, K), dtype=bool)                    # smoe.py:315
+    f0 = forward(p, target, coords, active, cfg, loss_w, T)
+    active = f0["active_new"]
+    loss0 = f0["loss"].copy()
+    best_loss = f0["loss"].copy()
+    best = {k: v.copy() for k, v in p.items()}
+    stopped = np.zeros((B,), dtype=bool)
+    hist = {"iter": [0], "loss": [f0["loss"].copy()], "sse": [f0["sse"].copy()]}
+    trace = []
+    for i in range(1, n_iters + 1):
+        f = forward(p, target, coords, active, cfg, loss_w, T, want_grads=True)
+        # reference order: pass (loss at current params) -> prune -> Adam -> divergence test
+        active = np.where(stopped[:, None], active, f["active_new"])
+        p = adam_step(p, f["grads"], state, cfg, T, frozen=stopped)
+        bad = np.logical_or(np.isnan(f["loss"]), f["loss"] + 1 > (loss0 + 100) * 10)
+        stopped = np.logical_or(stopped, bad)
+        if record_every and i % record_every == 0:
+            trace.append((i, f["loss"].copy(), f["sse"].copy()))
+        if i % ukl_iter == 0:
+            active = readmit(p, active, cfg, T)
+        if i % val_iter == 0:
+            fv = forward(p, target, coords, active, cfg, loss_w, T)
+            active = fv["active_new"]
+            better = fv["loss"] < best_loss
+            best_loss = np.where(better, fv["loss"], best_loss)
+            for k in best:
+                bm = better.reshape((-1,) + (1,) * (p[k].ndim - 1))
+                best[k] = np.where(bm, p[k], best[k])
+            hist["iter"].append(i)
+            hist["loss"].append(fv["loss"].copy())
+            hist["sse"].append(fv["sse"].copy())
+    info = {"active": active, "best": best, "best_loss": best_loss, "loss0": loss0,
+            "stopped": stopped, "hist": hist, "trace": trace}
+    return p, state, info
+
+
+def psnr_from_sse(sse_total: float, n_values: int) -> float:
+    """plotter.py:14-15 with mse_op of smoe.py:1053: 10*log10((2^p)^2 / (mean(diff^2)*(2^p)^2))."""
+    return float(-10.0 * np.log10(sse_total / n_values))
+
+
+# --------------------------------------------------------------------------
+# deterministic synthetic blocks
+# --------------------------------------------------------------------------
+def synthetic_blocks(B: int, block_shape: Sequence[int], C: int, seed: int) -> np.ndarray:
+    """Random oriented step edge + linear ramp + noise, rounded to uint8 and /255
+    (mirrors utils.py:126-128).  Returns (B, *block_shape, C) float32."""
+    rng = np.random.default_rng(seed)
+    d = len(block_shape)
+    axes = [np.linspace(0, 1, s) for s in block_shape]
+    grids = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1)          # (*shape, d)
+    normal = rng.normal(size=(B, d))
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    offset = rng.uniform(0.25, 0.75, size=(B,))
+    lo = rng.uniform(0.1, 0.9, size=(B, C))
+    hi = rng.uniform(0.1, 0.9, size=(B, C))
+    slope = rng.uniform(-0.3, 0.3, size=(B, d, C))
+    g = grids.reshape((1,) + grids.shape)
+    proj = np.einsum("b...l,bl->b...", np.broadcast_to(g, (B,) + grids.shape) - 0.5, normal) + 0.5
+    side = (proj > offset.reshape((B,) + (1,) * d)).astype(np.float64)
+    ex = (B,) + (1,) * d + (C,)
+    img = lo.reshape(ex) * (1 - side[..., None]) + hi.reshape(ex) * side[..., None]
+    img = img + np.einsum("...l,blc->b...c", grids - 0.5, slope)
+    img = img + rng.normal(scale=2 / 255, size=img.shape)
+    img = np.clip(img, 0, 1)
+    return (np.round(img * 255).astype(np.uint8).astype(np.float32) / np.float32(255.))

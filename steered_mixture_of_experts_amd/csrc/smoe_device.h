@@ -1,0 +1,99 @@
+// smoe_device.h -- argument blocks shared by the kernels (smoe_kernels.hip) and the
+// C-ABI host layer (smoe_capi.hip).  Internal; the public surface is include/smoe_hip.h.
+#ifndef SMOE_DEVICE_H
+#define SMOE_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "smoe_hip.h"
+
+namespace smoe {
+
+// Block-independent constants of the forward / loss maths.
+struct KernelConsts {
+    float tau;          // 0.5 / 2^p                       smoe.py:825
+    float epsm;         // margin / 2^p                    smoe.py:931
+    float scale;        // 1 / (2^p - 1)                   fake_quant nudged scale, smoe.py:899
+    float inv_scale;    // 1 / scale
+    float nudged_max;   // (2^p - 1) * scale
+    float cw[SMOE_MAX_CHANNELS];  // per-channel loss weight / N   smoe.py:933-937
+    float n_dis;        // sqrt((2 pi)^d)                  smoe.py:812
+    int use_det;        // smoe.py:809
+    int train_gammas;   // smoe.py:841
+};
+
+struct FitArgs {
+    const float* target;      // [B,C,N]
+    const float* loss_w;      // [B,N] or null
+    smoe_params p, m, v;
+    float* loss_out;          // [B] or null
+    float* sse_out;           // [B] or null
+    uint32_t* active;         // [B]
+    uint32_t* diverged;       // [B] or null
+    const float* loss0;       // [B] or null
+    const float* coords;      // [D][N]
+    int B, N, n_iters;
+    float b1p, b2p, beta1, beta2, eps;
+    float lr_expert, lr_pis, lr_steer;
+    int train_pis, train_musx;
+    float clip;
+    float reg_pi;             // pis_l1 / start_pis
+    float reg_u;              // u_l1
+    KernelConsts kc;
+};
+
+struct FwdArgs {
+    const float* target;
+    const float* loss_w;
+    smoe_params p;
+    float* recon;             // [B,C,N] or null
+    uint8_t* argmax;          // [B,N] or null
+    float* gate_w;            // [B,K,N] or null
+    float* loss;              // [B] or null
+    float* sse;               // [B] or null
+    uint32_t* active;         // [B]
+    const float* coords;
+    int B, N, update_active;
+    float reg_pi, reg_u;
+    KernelConsts kc;
+};
+
+struct ReadmitArgs {
+    smoe_params p;
+    uint32_t* active;
+    const float* probes;      // [D][3] = {min, max, mid} per axis
+    int B, K;
+};
+
+struct BestArgs {
+    const float* loss;
+    float* best_loss;
+    smoe_params p, best;
+    int B, K, D, C;
+};
+
+struct ReduceArgs {
+    const float* loss;
+    const float* sse;
+    const uint32_t* active;
+    double* out;
+    int B, N;
+};
+
+struct Variant {
+    int D, C, K, G, W;
+    const char* name;
+    hipError_t (*fit)(const FitArgs&, hipStream_t);
+    hipError_t (*fwd)(const FwdArgs&, hipStream_t);
+    size_t (*lds_bytes)(int N, bool has_lw);
+};
+
+const Variant* variants(int* count);
+hipError_t launch_readmit(const ReadmitArgs& a, int D, hipStream_t st);
+hipError_t launch_best(const BestArgs& a, hipStream_t st);
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
+
+}  // namespace smoe
+#endif

@@ -1,0 +1,850 @@
+// smoe_kernels.hip -- CDNA4 (gfx950) kernels of the per-block SMoE hot path.
+//
+// What one workgroup does: WAVES wavefronts, each wavefront owns 64/G image blocks
+// (G lanes per block, N/G pixels per lane).  The block's parameters live in LDS
+// (broadcast reads at the top of every iteration) and in registers during the pixel
+// loop; targets / coordinates are staged once per launch into LDS with coalesced HBM
+// reads; the K*P gradient sums are reduced across the G lanes through an LDS transpose
+// (every lane finishes ONE sum per pass: "owner" lanes), the owner applies TF1-Adam to
+// its parameter and publishes it back to LDS.  No inter-workgroup communication.
+//
+// Maths: SURVEY.md Appendix A; reference lines are cited at each step
+// (paths relative to /root/reference).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smoe_device.h"
+
+namespace smoe {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS hand-off between lanes of ONE wavefront: DS ops of a wave execute in order,
+    // so only compiler ordering + completion of the stores is required.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
+constexpr int tri_index(int l, int m) { return l * (l + 1) / 2 + m; }   // l >= m
+
+// Packed per-block parameter vector: for every kernel k
+//   [ pi | mu[0..D) | A lower-tri row-major (l>=m) | nu[0..C) | gamma[l][c] ]
+// Gradient sums use the same indexing ("slot j <-> packed parameter j"); three kinds
+// of extra slots follow: loss, sse, and the K influence counters (smoe.py:829).
+template <int D, int C, int K>
+struct Layout {
+    static constexpr int TRI = D * (D + 1) / 2;
+    static constexpr int O_PI = 0;
+    static constexpr int O_MU = 1;
+    static constexpr int O_A = 1 + D;
+    static constexpr int O_NU = O_A + TRI;
+    static constexpr int O_GA = O_NU + C;
+    static constexpr int PK = O_GA + D * C;
+    static constexpr int NPAR = K * PK;
+    static constexpr int S_LOSS = NPAR;
+    static constexpr int S_SSE = NPAR + 1;
+    static constexpr int S_CNT = NPAR + 2;
+    static constexpr int NSLOT = NPAR + 2 + K;
+    // LDS image of one block: packed params, K active flags, frozen flag
+    static constexpr int LP_ACT = NPAR;
+    static constexpr int LP_FROZEN = NPAR + K;
+    static constexpr int LP_STRIDE = round_up(NPAR + K + 1, 4);
+};
+
+// Where packed parameter j of block b lives in the reference's tensors
+// (get_params layout, smoe.py:1795-1800).  tensor: 0 pis 1 musX 2 A_diagonal 3 A_corr
+// 4 gamma_e 5 nu_e.
+template <int D, int C, int K>
+__device__ __forceinline__ void decode_slot(int j, int b, int& tensor, long& off, int& kern) {
+    using Lt = Layout<D, C, K>;
+    const int k = j / Lt::PK;
+    const int o = j - k * Lt::PK;
+    const long bk = (long)b * K + k;
+    kern = k;
+    if (o == Lt::O_PI) {
+        tensor = 0; off = bk;
+    } else if (o < Lt::O_A) {
+        tensor = 1; off = bk * D + (o - Lt::O_MU);
+    } else if (o < Lt::O_NU) {
+        const int t = o - Lt::O_A;
+        int l = 0;
+        while ((l + 1) * (l + 2) / 2 <= t) ++l;
+        const int m = t - l * (l + 1) / 2;
+        tensor = (l == m) ? 2 : 3;
+        off = (bk * D + l) * D + m;
+    } else if (o < Lt::O_GA) {
+        tensor = 5; off = bk * C + (o - Lt::O_NU);
+    } else {
+        const int t = o - Lt::O_GA;     // l*C + c
+        tensor = 4; off = bk * (D * C) + t;
+    }
+}
+
+__device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
+    switch (tensor) {
+        case 0: return s.pis;
+        case 1: return s.musX;
+        case 2: return s.A_diagonal;
+        case 3: return s.A_corr;
+        case 4: return s.gamma_e;
+        default: return s.nu_e;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-pixel forward (+ optional backward accumulation)
+// ---------------------------------------------------------------------------
+template <int D, int C, int K>
+struct BlockRegs {
+    using Lt = Layout<D, C, K>;
+    float P[Lt::LP_STRIDE];   // packed params + flags, filled from LDS
+    float coef[K];            // pi * prod diag(A) / sqrt((2pi)^d), 0 when the kernel is inactive
+    float invpi[K];           // 1/pi (0 when inactive)
+    float invdiag[K][D];      // 1/A[l][l]
+
+    __device__ __forceinline__ float pi(int k) const { return P[k * Lt::PK + Lt::O_PI]; }
+    __device__ __forceinline__ float mu(int k, int l) const { return P[k * Lt::PK + Lt::O_MU + l]; }
+    __device__ __forceinline__ float A(int k, int l, int m) const { return P[k * Lt::PK + Lt::O_A + tri_index(l, m)]; }
+    __device__ __forceinline__ float nu(int k, int c) const { return P[k * Lt::PK + Lt::O_NU + c]; }
+    __device__ __forceinline__ float ga(int k, int l, int c) const { return P[k * Lt::PK + Lt::O_GA + l * C + c]; }
+    __device__ __forceinline__ bool flag(int k) const { return P[Lt::LP_ACT + k] != 0.0f; }
+    __device__ __forceinline__ bool frozen() const { return P[Lt::LP_FROZEN] != 0.0f; }
+
+    __device__ __forceinline__ void load(const float* __restrict__ lds_block) {
+        const float4* src = reinterpret_cast<const float4*>(lds_block);
+#pragma unroll
+        for (int i = 0; i < Lt::LP_STRIDE / 4; ++i) {
+            const float4 q = src[i];
+            P[4 * i + 0] = q.x; P[4 * i + 1] = q.y; P[4 * i + 2] = q.z; P[4 * i + 3] = q.w;
+        }
+    }
+
+    // smoe.py:480,738 (bool_mask = kernel_list & pis>0), 809-819 (determinant factor, * pis)
+    __device__ __forceinline__ void derive(const KernelConsts& kc) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool act = flag(k) && (pi(k) > 0.0f);
+            float det = 1.0f;
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                det *= A(k, l, l);
+                invdiag[k][l] = act ? fast_rcp(A(k, l, l)) : 0.0f;
+            }
+            const float nq = kc.use_det ? det / kc.n_dis : 1.0f;   // n_quo = n_div / n_dis
+            coef[k] = act ? nq * pi(k) : 0.0f;
+            invpi[k] = act ? fast_rcp(pi(k)) : 0.0f;
+        }
+    }
+};
+
+template <int D, int C, int K>
+struct PixelOut {
+    float w[K];     // gate
+    float wt[K];    // masked gate
+    float q[C];     // quantised reconstruction
+    float y[C];     // pre-clip blend
+};
+
+// One pixel.  TRAIN: accumulate raw gradient sums into acc[] (layout = packed params,
+// "raw" meaning before the per-lane linear post-transform, see finish_partials).
+template <int D, int C, int K, bool TRAIN>
+__device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
+                                      const float (&x)[D], const float (&t)[C], float lw,
+                                      float* __restrict__ acc, PixelOut<D, C, K>& o) {
+    using Lt = Layout<D, C, K>;
+    float r[K][D], z[K][D], g[K];
+    float S = 0.0f;
+    // smoe.py:777-782,796,807: r = x - mu ; z = A^T r ; n = exp(-maha/2)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float maha = 0.0f;
+#pragma unroll
+        for (int l = 0; l < D; ++l) r[k][l] = x[l] - R.mu(k, l);
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float zz = r[k][m] * R.A(k, m, m);
+#pragma unroll
+            for (int l = m + 1; l < D; ++l) zz = fmaf(r[k][l], R.A(k, l, m), zz);
+            z[k][m] = zz;
+            maha = fmaf(zz, zz, maha);
+        }
+        g[k] = R.coef[k] * fast_exp2(maha * -0.72134752044448170368f);   // exp(-maha/2)
+        S += g[k];
+    }
+    // smoe.py:820-827: normalise, floor 1e-11, min-influence mask
+    const float Sm = fmaxf(S, 10e-12f);
+    const float inv = fast_rcp(Sm);
+    const bool passS = S > 10e-12f;
+    float e[K][C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) o.y[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        o.w[k] = g[k] * inv;
+        const bool M = o.w[k] > kc.tau;
+        o.wt[k] = M ? o.w[k] : 0.0f;
+        if (TRAIN || true) acc[Lt::S_CNT + k] += M ? 1.0f : 0.0f;
+        // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float ee = R.nu(k, c);
+            if (kc.train_gammas) {
+#pragma unroll
+                for (int l = 0; l < D; ++l) ee = fmaf(R.ga(k, l, c), x[l], ee);
+            }
+            e[k][c] = ee;
+            o.y[c] = fmaf(o.wt[k], ee, o.y[c]);
+        }
+    }
+    // smoe.py:857,899 (clip + fake quant), 905-937 (mse / margin loss)
+    float Gc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float yc = fminf(fmaxf(o.y[c], 0.0f), 1.0f);
+        const float cl = fminf(yc, kc.nudged_max);
+        o.q[c] = floorf(fmaf(cl, kc.inv_scale, 0.5f)) * kc.scale;
+        const float diff = o.q[c] - t[c];
+        const float ad = fabsf(diff) - kc.epsm;
+        acc[Lt::S_SSE] = fmaf(diff, diff, acc[Lt::S_SSE]);
+        acc[Lt::S_LOSS] = fmaf(kc.cw[c] * lw, ad * ad, acc[Lt::S_LOSS]);
+        if (TRAIN) {
+            const bool inside = (o.y[c] >= 0.0f) && (o.y[c] <= 1.0f);
+            const float sg = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
+            Gc[c] = inside ? (2.0f * kc.cw[c] * lw) * ad * sg : 0.0f;
+        }
+    }
+    if (!TRAIN) return;
+    // ---- reverse pass, SURVEY Appendix A.4 (tf.gradients, smoe.py:1148) -------
+    float h[K];
+    float dot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float hh = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) hh = fmaf(e[k][c], Gc[c], hh);
+        h[k] = (o.wt[k] > 0.0f) ? hh : 0.0f;
+        dot = fmaf(h[k], o.w[k], dot);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float u = passS ? o.w[k] * (h[k] - dot) : o.w[k] * h[k];
+        float* a = acc + k * Lt::PK;
+        a[Lt::O_PI] += u;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const float uz = u * z[k][m];
+            a[Lt::O_MU + m] += uz;                                   // sum u z_m   (-> A*(.) later)
+#pragma unroll
+            for (int l = m; l < D; ++l)
+                a[Lt::O_A + tri_index(l, m)] = fmaf(r[k][l], uz, a[Lt::O_A + tri_index(l, m)]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float wg = o.wt[k] * Gc[c];
+            a[Lt::O_NU + c] += wg;
+            if (kc.train_gammas) {
+#pragma unroll
+                for (int l = 0; l < D; ++l)
+                    a[Lt::O_GA + l * C + c] = fmaf(wg, x[l], a[Lt::O_GA + l * C + c]);
+            }
+        }
+    }
+}
+
+// Per-lane linear post-transform of the raw partial sums into partial gradients
+// (all maps are linear in the sums and use block-uniform parameters, so they commute
+// with the cross-lane reduction):
+//   d/dpi   = (sum u) / pi
+//   d/dmu_l = sum_m A[l][m] * (sum u z_m)                 (dm/dmu = -2 A z, dL/dm = -u/2)
+//   d/dA_lm = -(sum u r_l z_m) + [l==m, use_det] (sum u)/A_ll
+template <int D, int C, int K>
+__device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
+                                                float* __restrict__ acc) {
+    using Lt = Layout<D, C, K>;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float* a = acc + k * Lt::PK;
+        const float su = a[Lt::O_PI];
+        float suz[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) suz[m] = a[Lt::O_MU + m];
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            float gm = 0.0f;
+#pragma unroll
+            for (int m = 0; m <= l; ++m) gm = fmaf(R.A(k, l, m), suz[m], gm);
+            a[Lt::O_MU + l] = gm;
+        }
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+#pragma unroll
+            for (int m = 0; m <= l; ++m) {
+                float v = -a[Lt::O_A + tri_index(l, m)];
+                if (l == m && kc.use_det) v = fmaf(su, R.invdiag[k][l], v);
+                a[Lt::O_A + tri_index(l, m)] = v;
+            }
+        }
+        a[Lt::O_PI] = su * R.invpi[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS carve-up shared by the fit and forward kernels
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES>
+struct Tile {
+    using Lt = Layout<D, C, K>;
+    static constexpr int BPW = 64 / G;                  // blocks per wavefront
+    static constexpr int NB = WAVES * BPW;              // blocks per workgroup
+    static constexpr int CH = (G >= 32) ? G : 32;       // slots reduced per pass
+    static constexpr int ROW = 64 + 4;                  // padded row (bank-conflict-free b128 reads)
+    static constexpr int NCHUNK = (Lt::NSLOT + CH - 1) / CH;
+    static constexpr int SPL = (Lt::NSLOT + G - 1) / G; // owned slots per lane
+    static constexpr int THREADS = WAVES * 64;
+
+    // float offsets inside dynamic LDS
+    __host__ __device__ static int off_coords() { return 0; }
+    __host__ __device__ static int off_par(int N) { return round_up(D * N, 4); }
+    __host__ __device__ static int off_scratch(int N) { return off_par(N) + NB * Lt::LP_STRIDE; }
+    __host__ __device__ static int off_tgt(int N) { return off_scratch(N) + WAVES * CH * ROW; }
+    __host__ __device__ static int off_lw(int N) { return off_tgt(N) + NB * C * N; }
+    __host__ __device__ static size_t bytes(int N, bool has_lw) {
+        return sizeof(float) * (size_t)(off_lw(N) + (has_lw ? NB * N : 0));
+    }
+};
+
+template <int D, int C, int K, int G, int WAVES>
+__device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, const float* __restrict__ target,
+                                             const float* __restrict__ loss_w, int B, int N, int blk0,
+                                             float* __restrict__ lds) {
+    using T = Tile<D, C, K, G, WAVES>;
+    float* s_coords = lds + T::off_coords();
+    float* s_tgt = lds + T::off_tgt(N);
+    float* s_lw = lds + T::off_lw(N);
+    for (int i = threadIdx.x; i < D * N; i += T::THREADS) s_coords[i] = coords[i];
+    const int per = C * N;
+    for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) {
+        const int lb = i / per;
+        const int rem = i - lb * per;
+        const int b = min(blk0 + lb, B - 1);
+        s_tgt[i] = target[(size_t)b * per + rem];
+    }
+    if (loss_w != nullptr) {
+        for (int i = threadIdx.x; i < T::NB * N; i += T::THREADS) {
+            const int lb = i / N;
+            const int rem = i - lb * N;
+            const int b = min(blk0 + lb, B - 1);
+            s_lw[i] = loss_w[(size_t)b * N + rem];
+        }
+    }
+}
+
+// Cross-lane reduction of acc[0..NSLOT) over the G lanes of a block; lane `sub` ends up
+// with the totals of slots sub, sub+G, ... in total[].
+template <int D, int C, int K, int G, int WAVES>
+__device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, float* __restrict__ scratch_wave,
+                                             int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
+    using T = Tile<D, C, K, G, WAVES>;
+    using Lt = Layout<D, C, K>;
+    const int grp = lane / G;
+    const int sub = lane - grp * G;
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) total[s] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < T::NCHUNK; ++c) {
+#pragma unroll
+        for (int a = 0; a < T::CH; ++a) {
+            if (c * T::CH + a < Lt::NSLOT) scratch_wave[a * T::ROW + lane] = acc[c * T::CH + a];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            if ((s * G) / T::CH == c) {            // compile-time: which pass holds this lane's s-th slot
+                const int j = sub + s * G;
+                if (j < Lt::NSLOT) {
+                    const int a = j - c * T::CH;
+                    const float4* row = reinterpret_cast<const float4*>(scratch_wave + a * T::ROW + grp * G);
+                    float4 sum = row[0];
+#pragma unroll
+                    for (int i = 1; i < G / 4; ++i) {
+                        const float4 q = row[i];
+                        sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+                    }
+                    total[s] = (sum.x + sum.y) + (sum.z + sum.w);
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
+    using Lt = Layout<D, C, K>;
+    using T = Tile<D, C, K, G, WAVES>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int B = a.B;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G;
+    const int sub = lane - grp * G;
+    const int blk0 = blockIdx.x * T::NB;
+    const int lb = wave * T::BPW + grp;
+    const int b_raw = blk0 + lb;
+    const bool valid_b = b_raw < B;
+    const int b = valid_b ? b_raw : B - 1;
+
+    float* s_coords = lds + T::off_coords();
+    float* s_par = lds + T::off_par(N) + lb * Lt::LP_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N) + lb * (C * N);
+    const float* s_lw = lds + T::off_lw(N) + lb * N;
+    const bool has_lw = a.loss_w != nullptr;
+
+    stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+
+    // ---- owner set-up: this lane owns packed slots sub, sub+G, ... of its block --------
+    float pv[T::SPL], mv[T::SPL], vv[T::SPL], lr[T::SPL], reg[T::SPL];
+    long goff[T::SPL];
+    int gtensor[T::SPL], gkern[T::SPL];
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        const int j = sub + s * G;
+        pv[s] = mv[s] = vv[s] = lr[s] = reg[s] = 0.0f;
+        goff[s] = 0; gtensor[s] = -1; gkern[s] = 0;
+        if (j < Lt::NPAR) {
+            int tensor, kern; long off;
+            decode_slot<D, C, K>(j, b, tensor, off, kern);
+            gtensor[s] = tensor; goff[s] = off; gkern[s] = kern;
+            pv[s] = pick(a.p, tensor)[off];
+            mv[s] = pick(a.m, tensor)[off];
+            vv[s] = pick(a.v, tensor)[off];
+            // optimizer groups, smoe.py:1102-1104; untrainable variables dropped, 1112-1117
+            lr[s] = (tensor == 0) ? a.lr_pis : ((tensor == 2 || tensor == 3) ? a.lr_steer : a.lr_expert);
+            if (tensor == 0 && !a.train_pis) lr[s] = 0.0f;
+            if (tensor == 1 && !a.train_musx) lr[s] = 0.0f;
+            if (tensor == 4 && !a.kc.train_gammas) lr[s] = 0.0f;
+            reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? a.reg_u : 0.0f);   // smoe.py:1027,1044
+            s_par[j] = pv[s];
+        } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+            const int k = j - Lt::S_CNT;
+            s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
+        } else if (j == Lt::S_LOSS) {
+            s_par[Lt::LP_FROZEN] = (a.diverged != nullptr && a.diverged[b] != 0u) ? 1.0f : 0.0f;
+        }
+    }
+    const float loss0 = (a.loss0 != nullptr) ? a.loss0[b] : 0.0f;
+    float last_loss = 0.0f, last_sse = 0.0f;
+    __syncthreads();
+
+    float b1p = a.b1p, b2p = a.b2p;
+    BlockRegs<D, C, K> R;
+    const int pxl = (N + G - 1) / G;
+
+    for (int it = 0; it < a.n_iters; ++it) {
+        R.load(s_par);
+        R.derive(a.kc);
+        const bool frozen = R.frozen();
+
+        float acc[Lt::NSLOT];
+#pragma unroll
+        for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
+
+        for (int i = 0; i < pxl; ++i) {
+            const int n = i * G + sub;
+            if (n < N) {
+                float x[D], t[C];
+#pragma unroll
+                for (int l = 0; l < D; ++l) x[l] = s_coords[l * N + n];
+#pragma unroll
+                for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+                const float lw = has_lw ? s_lw[n] : 1.0f;
+                PixelOut<D, C, K> o;
+                pixel<D, C, K, true>(R, a.kc, x, t, lw, acc, o);
+            }
+        }
+        finish_partials<D, C, K>(R, a.kc, acc);
+
+        float total[T::SPL];
+        reduce_slots<D, C, K, G, WAVES>(acc, s_scratch, lane, total);
+
+        // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
+        const float one_m_b1p = 1.0f - b1p;
+        const float sq = sqrtf(1.0f - b2p);
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j < Lt::NPAR) {
+                if (lr[s] != 0.0f && !frozen) {
+                    float gsum = total[s];
+                    if (reg[s] != 0.0f) {
+                        const int k = gkern[s];
+                        const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (s_par[k * Lt::PK + Lt::O_PI] > 0.0f);
+                        if (act) gsum += reg[s];
+                    }
+                    if (a.clip > 0.0f) gsum = fminf(fmaxf(gsum, -a.clip), a.clip);
+                    const float alpha = lr[s] * sq / one_m_b1p;
+                    mv[s] = mv[s] + (gsum - mv[s]) * (1.0f - a.beta1);
+                    vv[s] = vv[s] + (gsum * gsum - vv[s]) * (1.0f - a.beta2);
+                    pv[s] = pv[s] - (mv[s] * alpha) / (sqrtf(vv[s]) + a.eps);
+                }
+            } else if (j == Lt::S_LOSS) {
+                float lossv = total[s];
+                if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool act = R.flag(k) && (R.pi(k) > 0.0f);
+                        if (act) {
+                            lossv += a.reg_pi * R.pi(k);
+#pragma unroll
+                            for (int l = 0; l < D; ++l) lossv += a.reg_u * R.A(k, l, l);
+                        }
+                    }
+                }
+                if (!frozen) {
+                    last_loss = lossv;
+                    const bool bad = (lossv != lossv) ||
+                                     (a.loss0 != nullptr && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f));
+                    if (bad) s_par[Lt::LP_FROZEN] = 1.0f;     // takes effect from the next iteration
+                }
+            } else if (j == Lt::S_SSE) {
+                if (!frozen) last_sse = total[s];
+            }
+        }
+        wave_lds_sync();   // every lane has consumed the old flags / params
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j < Lt::NPAR) {
+                s_par[j] = pv[s];
+            } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+                if (!frozen) s_par[Lt::LP_ACT + (j - Lt::S_CNT)] = (total[s] > 0.0f) ? 1.0f : 0.0f;
+            }
+        }
+        wave_lds_sync();
+        b1p *= a.beta1;
+        b2p *= a.beta2;
+    }
+
+    // ---- write back -----------------------------------------------------------
+    if (valid_b) {
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j < Lt::NPAR) {
+                pick(a.p, gtensor[s])[goff[s]] = pv[s];
+                pick(a.m, gtensor[s])[goff[s]] = mv[s];
+                pick(a.v, gtensor[s])[goff[s]] = vv[s];
+            } else if (j == Lt::S_LOSS) {
+                if (a.loss_out != nullptr && a.n_iters > 0) a.loss_out[b] = last_loss;
+                if (a.diverged != nullptr) a.diverged[b] = (s_par[Lt::LP_FROZEN] != 0.0f) ? 1u : 0u;
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int k = 0; k < K; ++k) mask |= (s_par[Lt::LP_ACT + k] != 0.0f) ? (1u << k) : 0u;
+                a.active[b] = mask;
+            } else if (j == Lt::S_SSE) {
+                if (a.sse_out != nullptr && a.n_iters > 0) a.sse_out[b] = last_sse;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward (evaluation) kernel
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
+    using Lt = Layout<D, C, K>;
+    using T = Tile<D, C, K, G, WAVES>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int B = a.B;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G;
+    const int sub = lane - grp * G;
+    const int blk0 = blockIdx.x * T::NB;
+    const int lb = wave * T::BPW + grp;
+    const int b_raw = blk0 + lb;
+    const bool valid_b = b_raw < B;
+    const int b = valid_b ? b_raw : B - 1;
+
+    float* s_coords = lds + T::off_coords();
+    float* s_par = lds + T::off_par(N) + lb * Lt::LP_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N) + lb * (C * N);
+    const float* s_lw = lds + T::off_lw(N) + lb * N;
+    const bool has_lw = a.loss_w != nullptr;
+
+    stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        const int j = sub + s * G;
+        if (j < Lt::NPAR) {
+            int tensor, kern; long off;
+            decode_slot<D, C, K>(j, b, tensor, off, kern);
+            s_par[j] = pick(a.p, tensor)[off];
+        } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+            const int k = j - Lt::S_CNT;
+            s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
+        } else if (j == Lt::S_LOSS) {
+            s_par[Lt::LP_FROZEN] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    BlockRegs<D, C, K> R;
+    R.load(s_par);
+    R.derive(a.kc);
+
+    float acc[Lt::NSLOT];
+#pragma unroll
+    for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
+
+    const int pxl = (N + G - 1) / G;
+    for (int i = 0; i < pxl; ++i) {
+        const int n = i * G + sub;
+        if (n < N) {
+            float x[D], t[C];
+#pragma unroll
+            for (int l = 0; l < D; ++l) x[l] = s_coords[l * N + n];
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+            const float lw = has_lw ? s_lw[n] : 1.0f;
+            PixelOut<D, C, K> o;
+            pixel<D, C, K, false>(R, a.kc, x, t, lw, acc, o);
+            if (valid_b) {
+                if (a.recon != nullptr) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) a.recon[((size_t)b * C + c) * N + n] = o.q[c];
+                }
+                if (a.gate_w != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) a.gate_w[((size_t)b * K + k) * N + n] = o.wt[k];
+                }
+                if (a.argmax != nullptr) {
+                    // tf.argmax over the kernels with influence (smoe.py:833): first maximum;
+                    // a pixel with no influential kernel resolves to the first listed kernel
+                    // of the block, which is only known after the block reduction -> 255 for now.
+                    float best = 0.0f;
+                    int arg = 255;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (o.wt[k] > best) { best = o.wt[k]; arg = k; }
+                    }
+                    a.argmax[(size_t)b * N + n] = (uint8_t)arg;
+                }
+            }
+        }
+    }
+
+    float total[T::SPL];
+    reduce_slots<D, C, K, G, WAVES>(acc, s_scratch, lane, total);
+
+    // publish the influence flags of the block through LDS (needed by every lane below)
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        const int j = sub + s * G;
+        if (j >= Lt::S_CNT && j < Lt::S_CNT + K) s_scratch[j - Lt::S_CNT + grp * 16] = (total[s] > 0.0f) ? 1.0f : 0.0f;
+    }
+    wave_lds_sync();
+    uint32_t newmask = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) newmask |= (s_scratch[k + grp * 16] != 0.0f) ? (1u << k) : 0u;
+
+    if (valid_b) {
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j == Lt::S_LOSS) {
+                float lossv = total[s];
+                if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool act = R.flag(k) && (R.pi(k) > 0.0f);
+                        if (act) {
+                            lossv += a.reg_pi * R.pi(k);
+#pragma unroll
+                            for (int l = 0; l < D; ++l) lossv += a.reg_u * R.A(k, l, l);
+                        }
+                    }
+                }
+                if (a.loss != nullptr) a.loss[b] = lossv;
+                if (a.update_active) a.active[b] = newmask;
+            } else if (j == Lt::S_SSE) {
+                if (a.sse != nullptr) a.sse[b] = total[s];
+            }
+        }
+        if (a.argmax != nullptr) {
+            const int first = (newmask != 0u) ? (__ffs(newmask) - 1) : 0;
+            for (int i = 0; i < pxl; ++i) {
+                const int n = i * G + sub;
+                if (n < N) {
+                    uint8_t* p8 = a.argmax + (size_t)b * N + n;
+                    if (*p8 == 255) *p8 = (uint8_t)first;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small per-block kernels
+// ---------------------------------------------------------------------------
+// update_kernel_list, smoe.py:2287-2365 (probe test smoe.py:806)
+template <int D>
+__global__ void readmit_kernel(ReadmitArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.B * a.K) return;
+    const int b = t / a.K;
+    const int k = t - b * a.K;
+    const long bk = (long)b * a.K + k;
+    float A[D][D];
+#pragma unroll
+    for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+            A[l][m] = (l == m) ? a.p.A_diagonal[(bk * D + l) * D + m] : ((l > m) ? a.p.A_corr[(bk * D + l) * D + m] : 0.0f);
+    int nprobe = 1;
+#pragma unroll
+    for (int l = 0; l < D; ++l) nprobe *= 3;
+    bool near = false;
+    for (int q = 0; q < nprobe; ++q) {
+        float r[D];
+        int rem = q;
+#pragma unroll
+        for (int l = D - 1; l >= 0; --l) {       // itertools.product order (last axis fastest); order is irrelevant to any()
+            const int sel = rem % 3;
+            rem /= 3;
+            r[l] = a.probes[l * 3 + sel] - a.p.musX[bk * D + l];
+        }
+        float maha = 0.0f;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float zz = 0.0f;
+#pragma unroll
+            for (int l = m; l < D; ++l) zz = fmaf(r[l], A[l][m], zz);
+            maha = fmaf(zz, zz, maha);
+        }
+        near = near || (maha < 800.0f);
+    }
+    if (near && a.p.pis[bk] > 0.0f) atomicOr(&a.active[b], 1u << k);
+}
+
+// checkpoint_best_op, smoe.py:861-896 (trigger 1574-1576), per block
+__global__ void best_kernel(BestArgs a) {
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const bool better = a.loss[b] < a.best_loss[b];
+    if (!better) return;
+    const int K = a.K, D = a.D, C = a.C;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) a.best.pis[(long)b * K + i] = a.p.pis[(long)b * K + i];
+    for (int i = threadIdx.x; i < K * D; i += blockDim.x) a.best.musX[(long)b * K * D + i] = a.p.musX[(long)b * K * D + i];
+    for (int i = threadIdx.x; i < K * D * D; i += blockDim.x) {
+        a.best.A_diagonal[(long)b * K * D * D + i] = a.p.A_diagonal[(long)b * K * D * D + i];
+        a.best.A_corr[(long)b * K * D * D + i] = a.p.A_corr[(long)b * K * D * D + i];
+    }
+    for (int i = threadIdx.x; i < K * D * C; i += blockDim.x) a.best.gamma_e[(long)b * K * D * C + i] = a.p.gamma_e[(long)b * K * D * C + i];
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) a.best.nu_e[(long)b * K * C + i] = a.p.nu_e[(long)b * K * C + i];
+    __syncthreads();
+    if (threadIdx.x == 0) a.best_loss[b] = a.loss[b];
+}
+
+// host accumulation of smoe.py:1758-1761 -> three doubles (single workgroup, deterministic order)
+__global__ void reduce_scalars_kernel(ReduceArgs a) {
+    __shared__ double s[3][256];
+    double l = 0.0, e = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+        if (a.loss) l += (double)a.loss[b] * (double)a.N;
+        if (a.sse) e += (double)a.sse[b];
+        if (a.active) c += (double)__popc(a.active[b]);
+    }
+    s[0][threadIdx.x] = l; s[1][threadIdx.x] = e; s[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s[0][threadIdx.x] += s[0][threadIdx.x + w];
+            s[1][threadIdx.x] += s[1][threadIdx.x + w];
+            s[2][threadIdx.x] += s[2][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { a.out[0] = s[0][0]; a.out[1] = s[1][0]; a.out[2] = s[2][0]; }
+}
+
+// ---------------------------------------------------------------------------
+// launchers + dispatch table
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit(const FitArgs& a, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
+    auto kern = fit_kernel<D, C, K, G, WAVES>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
+    auto kern = forward_kernel<D, C, K, G, WAVES>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C, int K, int G, int WAVES>
+size_t lds_bytes(int N, bool has_lw) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw); }
+
+#define SMOE_VARIANT(D, C, K, G, W) \
+    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W> }
+
+static const Variant g_variants[] = {
+    SMOE_VARIANT(2, 1, 4, 16, 4), SMOE_VARIANT(2, 1, 4, 64, 2),
+    SMOE_VARIANT(2, 3, 4, 16, 4), SMOE_VARIANT(2, 3, 4, 64, 2),
+    SMOE_VARIANT(2, 3, 8, 16, 2), SMOE_VARIANT(2, 3, 8, 64, 2),
+    SMOE_VARIANT(3, 3, 4, 16, 2), SMOE_VARIANT(3, 3, 4, 64, 2),
+    SMOE_VARIANT(2, 1, 8, 16, 4), SMOE_VARIANT(2, 1, 8, 64, 2),
+};
+
+const Variant* variants(int* count) {
+    *count = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
+    return g_variants;
+}
+
+hipError_t launch_readmit(const ReadmitArgs& a, int D, hipStream_t st) {
+    const int threads = 256;
+    const int grid = (a.B * a.K + threads - 1) / threads;
+    if (D == 2) hipLaunchKernelGGL(readmit_kernel<2>, dim3(grid), dim3(threads), 0, st, a);
+    else hipLaunchKernelGGL(readmit_kernel<3>, dim3(grid), dim3(threads), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_best(const BestArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(best_kernel, dim3(a.B), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_scalars_kernel, dim3(1), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace smoe

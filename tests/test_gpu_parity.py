@@ -1,0 +1,323 @@
+"""GPU parity: libsmoe_hip.so (through the C ABI) vs the CPU restatement in oracle/.
+
+Tolerances: single-pass quantities <= 1e-5 relative (<= 1e-6 absolute near
+0); quantised reconstruction identical except <= 1 LSB where y*255 sits within 1e-4 of a
+half-integer; one Adam step <= 1e-5; trajectories are judged against the fp32-vs-fp64
+sensitivity floor of the restatement itself (the reference's default hyper-parameters make
+the 200-step trajectory chaotic, see DESIGN.md "Parity").
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import smoe_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # block_shape, C, kernels_per_dim, use_yuv
+    ((16, 16), 1, [2, 2], False),
+    ((16, 16), 3, [2, 2], True),
+    ((32, 32), 3, [2, 4], True),
+    ((16, 16, 4), 3, [2, 2, 1], True),
+    ((16, 16), 1, [2, 4], False),
+]
+
+
+def _engine(shape, C, K, **kw):
+    from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
+    cfg = EngineConfig(block_shape=shape, channels=C, kernels=K, **kw)
+    return BlockEngine(cfg)
+
+
+def _to_dev(p):
+    return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in p.items()}
+
+
+def _to_host(p):
+    return {k: v.detach().cpu().numpy() for k, v in p.items()}
+
+
+def _mask_to_bits(active):
+    K = active.shape[1]
+    return (active.astype(np.uint32) << np.arange(K, dtype=np.uint32)[None, :]).sum(axis=1).astype(np.uint32)
+
+
+def _bits_to_mask(bits, K):
+    return ((bits[:, None] >> np.arange(K, dtype=np.uint32)[None, :]) & 1).astype(bool)
+
+
+def _setup(shape, C, kpd, yuv, B, seed, perturb=True, **cfgkw):
+    K = int(np.prod(kpd))
+    blk = o.synthetic_blocks(B, shape, C, seed)
+    p = o.init_params(blk, kpd)
+    rng = np.random.default_rng(seed + 1)
+    if perturb:
+        p["A_corr"] = (rng.normal(size=p["A_corr"].shape) * 1.5).astype(np.float32)
+        p["A_diagonal"] = (p["A_diagonal"] + rng.normal(size=p["A_diagonal"].shape)).astype(np.float32)
+        p["gamma_e"] = (rng.normal(size=p["gamma_e"].shape) * 0.1).astype(np.float32)
+        p["musX"] = (p["musX"] + rng.normal(size=p["musX"].shape) * 0.05).astype(np.float32)
+        p["pis"] = (p["pis"] * rng.uniform(0.5, 1.5, size=p["pis"].shape)).astype(np.float32)
+    cfg = o.OracleConfig(block_shape=shape, channels=C, kernels=K, use_yuv=yuv, **cfgkw)
+    coords = o.block_coords(shape)
+    tgt = blk.reshape(B, -1, C)
+    return cfg, p, coords, tgt, K
+
+
+def _planar(tgt):
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(tgt, (0, 2, 1)))).cuda()
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    return np.abs(a - b) <= atol + rtol * np.abs(b)
+
+
+def test_coords_match_numpy_linspace():
+    for shape in [(16, 16), (32, 32), (16, 16, 4), (7, 5), (1, 9)]:
+        C, K = 1, 4
+        if len(shape) == 3:
+            C = 3
+        eng = _engine(shape, C, K)
+        got = eng.coords().numpy()
+        want = o.block_coords(shape).T
+        assert np.array_equal(got, want), shape
+        eng.close()
+
+
+@pytest.mark.parametrize("shape,C,kpd,yuv", SHAPES)
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_forward_parity(shape, C, kpd, yuv, tiling):
+    B = 37      # ragged: not a multiple of the blocks per workgroup
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 100 + len(shape) + C, pis_l1=0.2, u_l1=0.003)
+    rng = np.random.default_rng(5)
+    active = rng.uniform(size=(B, K)) < 0.85
+    p["pis"][3, 0] = 0.0            # pis <= 0 kernels are absent (smoe.py:480)
+    p["pis"][4, 1] = -0.1
+    lw = rng.uniform(0.0, 1.0, size=(B, tgt.shape[1])).astype(np.float32)
+    ref = o.forward(p, tgt, coords, active, cfg, lw, np.float32)
+    ref64 = o.forward(p, tgt, coords, active, cfg, lw, np.float64)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.2, u_l1=0.003)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    out = eng.forward(_planar(tgt), dp, act, loss_w=torch.from_numpy(lw).cuda(), want_recon=True,
+                      want_argmax=True, want_gate=True)
+    torch.cuda.synchronize()
+    loss = out["loss"].cpu().numpy()
+    sse = out["sse"].cpu().numpy()
+    recon = np.transpose(out["recon"].cpu().numpy(), (0, 2, 1))
+    gate = out["gate_w"].cpu().numpy()
+    # gate weights: 1e-5 relative, except entries that sit on the influence threshold
+    tau = 0.5 / 256
+    near_tau = np.abs(ref64["w"] - tau) < 1e-6
+    ok = _close(gate, ref["wt"]) | near_tau
+    assert ok.all(), np.abs(gate - ref["wt"]).max()
+    # quantised reconstruction: identical up to 1 LSB at rounding ties
+    lsb = 1.0 / 255
+    d = np.abs(recon - ref["recon"])
+    tie = np.abs((np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0) < 1e-3
+    tie |= np.abs((np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0) > 1 - 1e-3
+    assert (d[~tie] < 1e-7).all(), d[~tie].max()
+    assert (d <= lsb * 1.0001).all()
+    clean = ~tie.any(axis=(1, 2))
+    assert clean.sum() > B // 2
+    assert _close(loss[clean], ref["loss"][clean], rtol=2e-5).all()
+    assert _close(sse[clean], ref["sse"][clean], rtol=2e-5).all()
+    # new active mask and argmax
+    new_act = _bits_to_mask(act.cpu().numpy().view(np.uint32), K)
+    unstable = near_tau.any(axis=2)
+    assert (new_act == ref["active_new"])[~unstable].all()
+    am = out["argmax"].cpu().numpy().astype(np.int64)
+    # ties between two kernels' gate values within rounding are allowed to differ
+    srt = np.sort(ref64["wt"], axis=1)
+    close_top = (srt[:, -1, :] - srt[:, -2, :]) < 1e-6
+    assert (am == ref["argmax"])[~close_top & ~unstable.any(axis=1)[:, None]].all()
+    eng.close()
+
+
+@pytest.mark.parametrize("shape,C,kpd,yuv", SHAPES)
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_one_step_parity(shape, C, kpd, yuv, tiling):
+    """One train iteration: gradients enter Adam's first step as sign-like updates, so
+    parity is checked on m (= 0.1*g, exposes the gradient itself), v and the parameters."""
+    B = 21
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 300 + len(shape) + C)
+    active = np.ones((B, K), dtype=bool)
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True)
+    ref64 = o.forward(p, tgt, coords, active, cfg, None, np.float64, want_grads=True)
+    st = o.new_adam_state(p)
+    p_ref = o.adam_step({k: v.copy() for k, v in p.items()}, ref["grads"], st, cfg, np.float32)
+
+    eng = _engine(shape, C, K, use_yuv=yuv)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    state = eng.new_adam_state(dp)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    loss = torch.zeros(B, device="cuda")
+    sse = torch.zeros(B, device="cuda")
+    eng.fit(_planar(tgt), dp, state, act, 1, loss_out=loss, sse_out=sse)
+    torch.cuda.synchronize()
+    assert state.step == 1
+    # blocks where a pixel sits on a quantisation tie or a gate on the threshold have
+    # discontinuous gradients; exclude them from the tight comparison (counted below)
+    y64 = np.clip(ref64["y"], 0, 1) * 255 + 0.5
+    frac = y64 % 1.0
+    tie = ((frac < 1e-3) | (frac > 1 - 1e-3)).any(axis=(1, 2))
+    tie |= (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    edge = ((np.abs(ref64["y"]) < 1e-6) | (np.abs(ref64["y"] - 1) < 1e-6)).any(axis=(1, 2))
+    clean = ~(tie | edge)
+    assert clean.sum() >= B // 2
+    assert _close(loss.cpu().numpy()[clean], ref["loss"][clean], rtol=2e-5).all()
+    m = _to_host(state.m)
+    got = _to_host(dp)
+    for name in o.PARAM_NAMES:
+        g_ref = ref["grads"][name][clean]
+        scale = np.abs(ref64["grads"][name][clean]).max() + 1e-30
+        g_got = m[name][clean] / 0.1
+        err = np.abs(g_got - g_ref).max() / scale
+        assert err < 2e-5, (name, err)
+        perr = np.abs(got[name][clean] - p_ref[name][clean])
+        # first Adam step is lr*sign(g) (eps aside): elements whose gradient is ~0 are ill-conditioned
+        strong = np.abs(ref64["grads"][name][clean]) > 1e-7 * scale + 1e-12
+        tol = 2e-5 * (np.abs(p_ref[name][clean]) + 1.0)
+        assert (perr[strong] <= tol[strong]).all(), (name, perr[strong].max())
+    eng.close()
+
+
+def test_short_trajectory_vs_sensitivity_floor():
+    """20 iterations at the reference's default learning rates: the GPU's deviation from
+    the fp32 restatement must be of the order of the restatement's own fp32-vs-fp64
+    deviation (the dynamics amplify rounding)."""
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 256
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 777, perturb=False)
+    n = 20
+    p32, _, i32 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float32)
+    p64, _, i64 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float64)
+    eng = _engine(shape, C, K)
+    dp = _to_dev(p)
+    state = eng.new_adam_state(dp)
+    act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
+    T = _planar(tgt)
+    eng.forward(T, dp, act, want_recon=False)          # iteration-0 eval pass prunes
+    eng.fit(T, dp, state, act, n)
+    out = eng.forward(T, dp, act, want_recon=False, update_active=False)
+    torch.cuda.synchronize()
+    got = _to_host(dp)
+    f32 = o.forward(p32, tgt, coords, i32["active"], cfg, None, np.float32)
+    f64 = o.forward(p64, tgt, coords, i64["active"], cfg, None, np.float64)
+    ps = lambda sse: -10 * np.log10(np.maximum(sse, 1e-12) / (tgt.shape[1] * C))
+    d_gpu = np.abs(ps(out["sse"].cpu().numpy()) - ps(f32["sse"]))
+    d_floor = np.abs(ps(f32["sse"]) - ps(f64["sse"]))
+    # median per-block PSNR deviation: same order as the floor, and small in absolute terms
+    assert np.median(d_gpu) <= max(3 * np.median(d_floor), 0.05), (np.median(d_gpu), np.median(d_floor))
+    assert abs(np.median(ps(out["sse"].cpu().numpy())) - np.median(ps(f32["sse"]))) < 0.05
+    for name in ("nu_e", "musX"):
+        dev = np.median(np.abs(got[name] - p32[name]))
+        floor = np.median(np.abs(p32[name] - p64[name]))
+        assert dev <= 5 * floor + 1e-4, (name, dev, floor)
+    eng.close()
+
+
+def test_gentle_lr_trajectory_tight():
+    """With a small steering learning rate the dynamics are well conditioned and the GPU
+    follows the restatement closely over 50 steps."""
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 64
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 991, perturb=False, lr_steer=1e-2)
+    n = 50
+    p32, st32, i32 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float32)
+    p64, _, _ = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float64)
+    eng = _engine(shape, C, K, lr_steer=1e-2)
+    dp = _to_dev(p)
+    state = eng.new_adam_state(dp)
+    act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
+    T = _planar(tgt)
+    eng.forward(T, dp, act, want_recon=False)
+    eng.fit(T, dp, state, act, n)
+    torch.cuda.synchronize()
+    got = _to_host(dp)
+    for name in o.PARAM_NAMES:
+        dev = np.abs(got[name] - p32[name])
+        floor = np.abs(p32[name] - p64[name])
+        assert np.median(dev) <= 3 * np.median(floor) + 1e-5, (name, np.median(dev), np.median(floor))
+    eng.close()
+
+
+def test_frozen_blocks_and_divergence_flag():
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 8
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 4242, perturb=False)
+    eng = _engine(shape, C, K)
+    dp = _to_dev(p)
+    before = _to_host(dp)
+    state = eng.new_adam_state(dp)
+    act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
+    div = torch.zeros(B, dtype=torch.int32, device="cuda")
+    div[2] = 1
+    loss0 = torch.full((B,), 1.0, device="cuda")
+    loss0[5] = -100.0 + 1e-4     # loss + 1 > (loss0 + 100) * 10 trips immediately
+    eng.fit(_planar(tgt), dp, state, act, 5, diverged=div, loss0=loss0)
+    torch.cuda.synchronize()
+    after = _to_host(dp)
+    d = div.cpu().numpy()
+    assert d[2] == 1 and d[5] == 1 and d[[0, 1, 3, 4, 6, 7]].sum() == 0
+    for name in o.PARAM_NAMES:
+        assert np.array_equal(after[name][2], before[name][2])
+    # block 5 took exactly one step (the diverging iteration's update is kept, smoe.py:1527-1570)
+    st = o.new_adam_state(p)
+    f = o.forward(p, tgt, coords, np.ones((B, K), bool), cfg, None, np.float32, want_grads=True)
+    p1 = o.adam_step({k: v.copy() for k, v in p.items()}, f["grads"], st, cfg, np.float32)
+    assert np.allclose(after["nu_e"][5], p1["nu_e"][5], atol=2e-6)
+    assert not np.allclose(after["nu_e"][0], p1["nu_e"][0], atol=1e-4)
+    eng.close()
+
+
+def test_update_kernel_list_and_best_and_reduce():
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 50
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 31337)
+    p["A_diagonal"][7] *= 40.0          # far kernels: maha at every probe >= 800 for some
+    p["pis"][9, 2] = 0.0
+    active = np.zeros((B, K), dtype=bool)
+    active[::2, 0] = True
+    want = o.readmit(p, active, cfg, np.float32)
+    eng = _engine(shape, C, K)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    eng.update_kernel_list(dp, act)
+    torch.cuda.synchronize()
+    got = _bits_to_mask(act.cpu().numpy().view(np.uint32), K)
+    assert np.array_equal(got, want)
+    assert not want[7].all() and not want[9, 2]
+    # best snapshot
+    loss = torch.rand(B, device="cuda")
+    best_loss = torch.full((B,), 0.5, device="cuda")
+    best = {k: torch.zeros_like(v) for k, v in dp.items()}
+    eng.checkpoint_best(loss, best_loss, dp, best)
+    torch.cuda.synchronize()
+    better = (loss < 0.5).cpu().numpy()
+    for name in o.PARAM_NAMES:
+        b = best[name].cpu().numpy()
+        assert np.array_equal(b[better], p[name][better].astype(np.float32))
+        assert not b[~better].any()
+    assert np.array_equal(best_loss.cpu().numpy(), np.where(better, loss.cpu().numpy(), 0.5).astype(np.float32))
+    # scalar reduction
+    sse = torch.rand(B, device="cuda")
+    r = eng.reduce_scalars(loss, sse, act).cpu().numpy()
+    assert abs(r[0] - float(loss.double().sum()) * 256) < 1e-6
+    assert abs(r[1] - float(sse.double().sum())) < 1e-9
+    assert r[2] == got.sum()
+    eng.close()
+
+
+def test_error_paths():
+    from steered_mixture_of_experts_amd import _lib
+    from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
+    with pytest.raises(_lib.SmoeError) as e:
+        BlockEngine(EngineConfig(block_shape=(16, 16), channels=2, kernels=5))
+    assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
+    eng = _engine((16, 16), 1, 4)
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(3, 1, 100, device="cuda"), eng.new_params(3), torch.zeros(3, dtype=torch.int32, device="cuda"))
+    eng.close()

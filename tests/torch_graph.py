@@ -1,0 +1,90 @@
+"""Independent torch restatement of the reference TF graph for ONE block, written
+op-for-op from smoe.py:732-937,1012-1053 (band_part assembly, the 4-operand
+einsum, boolean_mask of every parameter, straight-through fake-quant), used only
+to cross-check the numpy oracle's forward values and analytic gradients through
+``torch.autograd``.  Test infrastructure; not part of the product path.
+"""
+import math
+
+import torch
+
+
+class _FakeQuant01(torch.autograd.Function):
+    """tf.quantization.fake_quant_with_min_max_args(x, 0, 1, num_bits) with its
+    registered gradient (pass-through inside [nudged_min, nudged_max])."""
+
+    @staticmethod
+    def forward(ctx, x, bits):
+        levels = float(2 ** bits - 1)
+        scale = torch.tensor(1.0, dtype=x.dtype) / levels
+        inv = 1.0 / scale
+        nmax = levels * scale
+        ctx.save_for_backward((x >= 0) & (x <= nmax))
+        cl = torch.clamp(x, min=0.0, max=float(nmax))
+        return torch.floor(cl * inv + 0.5) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        (inside,) = ctx.saved_tensors
+        return g * inside.to(g.dtype), None
+
+
+def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0.5,
+                   use_determinant=True, use_yuv=False, train_gammas=True,
+                   pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None):
+    """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
+    with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
+    Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
+    pis_v, musX_v = params["pis"], params["musX"]
+    Ad_v, Ac_v = params["A_diagonal"], params["A_corr"]
+    gam_v, nu_v = params["gamma_e"], params["nu_e"]
+    K, d = musX_v.shape
+    C = nu_v.shape[1]
+    N = coords.shape[0]
+    dt = coords.dtype
+    # smoe.py:732-733  band_part(A_diagonal,0,0) + band_part(set_diag(A_corr,0),-1,0)
+    A = torch.diag_embed(torch.diagonal(Ad_v, dim1=-2, dim2=-1)) + torch.tril(Ac_v, diagonal=-1)
+    # smoe.py:480,738-753
+    bool_mask = kernel_list & (pis_v > 0)
+    indices = torch.arange(K)[bool_mask]
+    musX, nu_e, gamma_e, A, pis = musX_v[bool_mask], nu_v[bool_mask], gam_v[bool_mask], A[bool_mask], pis_v[bool_mask]
+    # smoe.py:777-782,796
+    x_sub_mu = (coords.unsqueeze(0) - musX.unsqueeze(1)).unsqueeze(-1)          # (K,N,d,1)
+    maha = torch.einsum("abli,alm,anm,abnj->ab", x_sub_mu, A, A, x_sub_mu)
+    n_exp = torch.exp(-0.5 * maha)                                               # smoe.py:807
+    if use_determinant:                                                          # smoe.py:809-815
+        n_div = torch.prod(torch.diagonal(A, dim1=-2, dim2=-1), dim=-1)
+        n_quo = n_div / math.sqrt((2 * math.pi) ** d)
+        Nk = n_quo.unsqueeze(1) * n_exp
+    else:
+        Nk = n_exp
+    n_w = Nk * pis.unsqueeze(-1)                                                 # smoe.py:819
+    n_w_norm = torch.sum(n_w, dim=0)
+    n_w_norm = torch.maximum(torch.tensor(10e-12, dtype=dt), n_w_norm)           # smoe.py:821
+    w_e = n_w / n_w_norm
+    infl = (w_e > 0.5 / (2 ** precision)).to(dt)                                 # smoe.py:825-826
+    w_e = w_e * infl
+    klb = infl.sum(dim=1) > 0                                                    # smoe.py:829
+    nu_t = nu_e.t().unsqueeze(-1)                                                # (C,K,1)
+    if train_gammas:                                                             # smoe.py:841-846
+        dom = coords.t().unsqueeze(0).repeat(C, 1, 1)                            # (C,d,N)
+        sloped = torch.matmul(gamma_e.permute(2, 0, 1), dom)                     # (C,K,N)
+        res = torch.sum(w_e * (sloped + nu_t), dim=1)
+    else:
+        res = torch.sum(w_e * nu_t, dim=1)
+    pre = res.t()
+    res = torch.clamp(res, 0.0, 1.0).t()                                         # smoe.py:857-858
+    res = _FakeQuant01.apply(res, precision)                                     # smoe.py:899
+    diff = res - target
+    mse = torch.mean(diff ** 2)
+    eps = margin / (2 ** precision)
+    lw = torch.ones((N, 1), dtype=dt) if loss_w is None else loss_w.reshape(N, 1)
+    lp = torch.clamp((diff.abs() - eps) ** 2, min=0.0) * lw                      # smoe.py:932
+    if use_yuv:
+        loss_pixel = 6 / 8 * lp[:, 0].mean() + 1 / 8 * lp[:, 1:].mean(dim=0).sum()
+    else:
+        loss_pixel = lp.mean()
+    k0 = K if start_pis is None else start_pis
+    loss = loss_pixel + pis_l1 * pis.sum() / k0 + u_l1 * torch.diagonal(A, dim1=-2, dim2=-1).sum()
+    return {"loss": loss, "mse_op": mse * (2 ** precision) ** 2, "res": res, "pre": pre,
+            "w_e": w_e, "indices": indices[klb], "bool_mask": bool_mask}
