@@ -192,7 +192,7 @@ def fake_quant01(y, precision, T):
 
 def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
             active: np.ndarray, cfg: OracleConfig, loss_w: Optional[np.ndarray] = None,
-            dtype=np.float32, want_grads: bool = False):
+            dtype=np.float32, want_grads: bool = False, q_override: Optional[np.ndarray] = None):
     """One pass of the reference graph over B independent blocks.
 
     p: parameter dict with leading B.  target: (B, N, C).  coords: (N, d).
@@ -200,6 +200,10 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     Returns a dict: y (pre-clip), w (gate), wt (masked gate), recon (quantised),
     loss (B,), sse (B,), mse_op (B,), active_new (B,K), argmax (B,N), num_pi (B,),
     and when ``want_grads`` the analytic gradients ``grads`` (dict like p).
+    ``q_override`` (B,N,C): use this quantised reconstruction instead of the computed one
+    when forming diff/loss/gradients (test hook: the 8-bit quantiser makes loss and
+    gradients discontinuous at rounding ties, so a checker feeds the implementation's own
+    lattice values here and checks the lattice values separately).
     """
     T = dtype
     B, N, C = target.shape
@@ -251,6 +255,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
         e = np.broadcast_to(nu[:, :, None, :], (B, K, N, C)).astype(T)
     y = np.sum(wt[..., None] * e, axis=1)                    # (B,N,C)
     q = fake_quant01(y, cfg.precision, T)                    # smoe.py:857,899
+    if q_override is not None:
+        q = q_override.astype(T)
 
     diff = q - t                                             # smoe.py:905
     sse = np.sum(np.square(diff), axis=(1, 2))               # (B,)

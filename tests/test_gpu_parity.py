@@ -112,17 +112,19 @@ def test_forward_parity(shape, C, kpd, yuv, tiling):
     near_tau = np.abs(ref64["w"] - tau) < 1e-6
     ok = _close(gate, ref["wt"]) | near_tau
     assert ok.all(), np.abs(gate - ref["wt"]).max()
-    # quantised reconstruction: identical up to 1 LSB at rounding ties
+    # quantised reconstruction: identical except <= 1 LSB where y*255 is within 2e-4 of a tie
     lsb = 1.0 / 255
     d = np.abs(recon - ref["recon"])
-    tie = np.abs((np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0) < 1e-3
-    tie |= np.abs((np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0) > 1 - 1e-3
+    frac = (np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie = (frac < 2e-4) | (frac > 1 - 2e-4)
     assert (d[~tie] < 1e-7).all(), d[~tie].max()
     assert (d <= lsb * 1.0001).all()
-    clean = ~tie.any(axis=(1, 2))
-    assert clean.sum() > B // 2
-    assert _close(loss[clean], ref["loss"][clean], rtol=2e-5).all()
-    assert _close(sse[clean], ref["sse"][clean], rtol=2e-5).all()
+    assert tie.mean() < 0.01
+    # loss / sse given the implementation's own lattice values (the quantiser makes them
+    # discontinuous at ties): tight for every block
+    refq = o.forward(p, tgt, coords, active, cfg, lw, np.float32, q_override=recon)
+    assert _close(loss, refq["loss"], rtol=2e-5).all(), np.abs(loss - refq["loss"]).max()
+    assert _close(sse, refq["sse"], rtol=2e-5).all()
     # new active mask and argmax
     new_act = _bits_to_mask(act.cpu().numpy().view(np.uint32), K)
     unstable = near_tau.any(axis=2)
@@ -143,31 +145,32 @@ def test_one_step_parity(shape, C, kpd, yuv, tiling):
     B = 21
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 300 + len(shape) + C)
     active = np.ones((B, K), dtype=bool)
-    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True)
-    ref64 = o.forward(p, tgt, coords, active, cfg, None, np.float64, want_grads=True)
-    st = o.new_adam_state(p)
-    p_ref = o.adam_step({k: v.copy() for k, v in p.items()}, ref["grads"], st, cfg, np.float32)
-
     eng = _engine(shape, C, K, use_yuv=yuv)
     eng.set_tiling(tiling)
     dp = _to_dev(p)
-    state = eng.new_adam_state(dp)
     act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    # the implementation's own lattice values at these parameters (forward kernel)
+    fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True, q_override=recon)
+    ref64 = o.forward(p, tgt, coords, active, cfg, None, np.float64, want_grads=True, q_override=recon)
+    st = o.new_adam_state(p)
+    p_ref = o.adam_step({k: v.copy() for k, v in p.items()}, ref["grads"], st, cfg, np.float32)
+    state = eng.new_adam_state(dp)
     loss = torch.zeros(B, device="cuda")
     sse = torch.zeros(B, device="cuda")
-    eng.fit(_planar(tgt), dp, state, act, 1, loss_out=loss, sse_out=sse)
+    eng.fit(T, dp, state, act, 1, loss_out=loss, sse_out=sse)
     torch.cuda.synchronize()
     assert state.step == 1
-    # blocks where a pixel sits on a quantisation tie or a gate on the threshold have
-    # discontinuous gradients; exclude them from the tight comparison (counted below)
-    y64 = np.clip(ref64["y"], 0, 1) * 255 + 0.5
-    frac = y64 % 1.0
-    tie = ((frac < 1e-3) | (frac > 1 - 1e-3)).any(axis=(1, 2))
-    tie |= (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    # exclude blocks with a gate value on the influence threshold or a blend on the clip
+    # edge (discontinuous gradient there); ties of the quantiser are handled by q_override
+    tie = (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
     edge = ((np.abs(ref64["y"]) < 1e-6) | (np.abs(ref64["y"] - 1) < 1e-6)).any(axis=(1, 2))
     clean = ~(tie | edge)
-    assert clean.sum() >= B // 2
+    assert clean.sum() >= (3 * B) // 4
     assert _close(loss.cpu().numpy()[clean], ref["loss"][clean], rtol=2e-5).all()
+    assert _close(sse.cpu().numpy()[clean], ref["sse"][clean], rtol=2e-5).all()
     m = _to_host(state.m)
     got = _to_host(dp)
     for name in o.PARAM_NAMES:
@@ -177,19 +180,23 @@ def test_one_step_parity(shape, C, kpd, yuv, tiling):
         err = np.abs(g_got - g_ref).max() / scale
         assert err < 2e-5, (name, err)
         perr = np.abs(got[name][clean] - p_ref[name][clean])
-        # first Adam step is lr*sign(g) (eps aside): elements whose gradient is ~0 are ill-conditioned
-        strong = np.abs(ref64["grads"][name][clean]) > 1e-7 * scale + 1e-12
-        tol = 2e-5 * (np.abs(p_ref[name][clean]) + 1.0)
-        assert (perr[strong] <= tol[strong]).all(), (name, perr[strong].max())
+        # first TF1-Adam step: delta = lr*g/(|g| + eps*sqrt(1-b1)... ) = lr*g/(|g| + 3.16e-7):
+        # an element's sensitivity to gradient noise dg is lr*e/(|g|+e)^2 with e = 1e-8/sqrt(1e-3)
+        lr = {"pis": cfg.lr_pis, "A_diagonal": cfg.lr_steer, "A_corr": cfg.lr_steer}.get(name, cfg.lr_expert)
+        e = 1e-8 / np.sqrt(1e-3)
+        gabs = np.abs(ref64["grads"][name][clean])
+        tol = 1e-6 * (np.abs(p_ref[name][clean]) + 1.0) + 2e-5 * lr + lr * (4e-6 * scale) * e / (gabs + e) ** 2
+        assert (perr <= tol).all(), (name, (perr / tol).max())
     eng.close()
 
 
 def test_short_trajectory_vs_sensitivity_floor():
-    """20 iterations at the reference's default learning rates: the GPU's deviation from
-    the fp32 restatement must be of the order of the restatement's own fp32-vs-fp64
-    deviation (the dynamics amplify rounding)."""
+    """20 iterations at the reference's default learning rates (A trained with lr 1.0 through
+    an 8-bit quantiser: rounding differences are amplified, DESIGN.md "Parity").  The GPU's
+    deviation from the fp32 restatement must not exceed the restatement's own fp32-vs-fp64
+    deviation, and the median block PSNR must agree within 0.05 dB."""
     shape, C, kpd = (16, 16), 1, [2, 2]
-    B = 256
+    B = 1024
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 777, perturb=False)
     n = 20
     p32, _, i32 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float32)
@@ -207,15 +214,15 @@ def test_short_trajectory_vs_sensitivity_floor():
     f32 = o.forward(p32, tgt, coords, i32["active"], cfg, None, np.float32)
     f64 = o.forward(p64, tgt, coords, i64["active"], cfg, None, np.float64)
     ps = lambda sse: -10 * np.log10(np.maximum(sse, 1e-12) / (tgt.shape[1] * C))
-    d_gpu = np.abs(ps(out["sse"].cpu().numpy()) - ps(f32["sse"]))
-    d_floor = np.abs(ps(f32["sse"]) - ps(f64["sse"]))
-    # median per-block PSNR deviation: same order as the floor, and small in absolute terms
-    assert np.median(d_gpu) <= max(3 * np.median(d_floor), 0.05), (np.median(d_gpu), np.median(d_floor))
-    assert abs(np.median(ps(out["sse"].cpu().numpy())) - np.median(ps(f32["sse"]))) < 0.05
-    for name in ("nu_e", "musX"):
+    g, a, b = ps(out["sse"].cpu().numpy()), ps(f32["sse"]), ps(f64["sse"])
+    d_gpu = np.median(np.abs(g - a))
+    d_floor = np.median(np.abs(a - b))
+    assert d_gpu <= 1.5 * d_floor + 0.005, (d_gpu, d_floor)
+    assert abs(np.median(g) - np.median(a)) < 0.05, (np.median(g), np.median(a))
+    for name in ("nu_e", "musX", "gamma_e", "pis", "A_diagonal", "A_corr"):
         dev = np.median(np.abs(got[name] - p32[name]))
         floor = np.median(np.abs(p32[name] - p64[name]))
-        assert dev <= 5 * floor + 1e-4, (name, dev, floor)
+        assert dev <= 2 * floor + 1e-6, (name, dev, floor)
     eng.close()
 
 
