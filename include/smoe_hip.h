@@ -153,6 +153,9 @@ int smoe_reduce_scalars(smoe_handle h, int32_t num_blocks, const float* loss, co
 /* Name of the kernel variant smoe_fit would launch for num_blocks (diagnostics / profiles). */
 const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks);
 
+/* Resident wavefronts per CU the runtime grants smoe_fit's kernel for num_blocks (diagnostics). */
+int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks);
+
 /* Force the lanes-per-block tiling (16, 64; 0 = automatic).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
 

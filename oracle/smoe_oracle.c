@@ -120,7 +120,7 @@ static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, con
             const float ad = fabsf(diff) - epsm;
             sse += diff * diff;
             loss_acc += cw[ch] * lwn * (ad * ad);
-            const int inside = (y[ch] >= 0.0f) && (y[ch] <= 1.0f);
+            const int inside = (y[ch] >= 0.0f) && (y[ch] <= 1.0f) && (y[ch] <= nudged_max);
             const float sg = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
             G[ch] = inside ? (2.0f * cw[ch] * lwn) * ad * sg : 0.0f;
         }

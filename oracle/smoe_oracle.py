@@ -281,7 +281,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
         return out
 
     # ---- analytic reverse pass ------------------------
-    inside = np.logical_and(y >= T(0), y <= T(1))            # clip + fake-quant STE
+    nudged_max = T(2 ** cfg.precision - 1) * (T(1) / T(2 ** cfg.precision - 1))
+    inside = np.logical_and(y >= T(0), y <= np.minimum(T(1), nudged_max))   # clip + fake-quant STE
     G = (cw[None, None, :] * T(2) * a * np.sign(diff) * lw[:, :, None]) * inside   # (B,N,C)
     # experts
     g_nu = np.einsum("bkn,bnc->bkc", wt, G)

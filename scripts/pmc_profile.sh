@@ -1,0 +1,30 @@
+#!/bin/bash
+# PMC passes for the fit kernel (each pass is its own rocprofv3 run; counters only with --kernel-trace).
+# usage: scripts/pmc_profile.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$OUT"
+run() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 100 --warmup 0 --no-cpu-baseline $BENCH_ARGS > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
+export BENCH_ARGS="${BENCH_ARGS:-}"
+run p1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+run p2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM
+run p3 FETCH_SIZE
+run p4 WRITE_SIZE
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out=sys.argv[1]
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+for f in glob.glob(out+'/*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k=r['Kernel_Name']
+        if 'fit_kernel' not in k and 'forward_kernel' not in k: continue
+        kk='fit' if 'fit_kernel' in k else 'fwd'
+        agg[kk][r['Counter_Name']]+=float(r['Counter_Value'])
+        cnt[(kk,r['Counter_Name'])]+=1
+for kk in agg:
+    print('==',kk)
+    for c,v in sorted(agg[kk].items()):
+        n=cnt[(kk,c)]
+        print(f'  {c:24s} total {v:.4g}  dispatches {n}  per-dispatch {v/n:.4g}')
+PY

@@ -22,7 +22,7 @@ SMOE_ERR_NO_DEVICE = -4
 EXPORTS = (
     "smoe_create", "smoe_destroy", "smoe_is_supported", "smoe_get_coords", "smoe_forward",
     "smoe_fit", "smoe_update_kernel_list", "smoe_checkpoint_best", "smoe_reduce_scalars",
-    "smoe_fit_variant", "smoe_set_tiling", "smoe_last_error", "smoe_abi_version",
+    "smoe_fit_variant", "smoe_fit_occupancy", "smoe_set_tiling", "smoe_last_error", "smoe_abi_version",
 )
 
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.smoe_reduce_scalars.argtypes = [vp, i32, fp, fp, fp, fp, vp]
     lib.smoe_fit_variant.argtypes = [vp, i32]
     lib.smoe_fit_variant.restype = C.c_char_p
+    lib.smoe_fit_occupancy.argtypes = [vp, i32]
     lib.smoe_set_tiling.argtypes = [vp, i32]
     lib.smoe_last_error.restype = C.c_char_p
     for name in EXPORTS:

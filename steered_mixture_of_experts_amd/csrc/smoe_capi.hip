@@ -161,7 +161,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     const float levels = (float)(two_p - 1.0);
     kc.scale = 1.0f / levels;                            // TF Nudge(): (max-min)/(quant_max-quant_min)
     kc.inv_scale = 1.0f / kc.scale;
-    kc.nudged_max = levels * kc.scale;
+    kc.nudged_max = fminf(1.0f, levels * kc.scale);      // combined clip_by_value(0,1) + nudged range
     const int C = cfg->channels;
     for (int c = 0; c < SMOE_MAX_CHANNELS; ++c) kc.cw[c] = 0.0f;
     for (int c = 0; c < C; ++c) {
@@ -203,6 +203,14 @@ const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks) {
     if (!h) return "";
     const smoe::Variant* v = find_variant(h, num_blocks, false);
     return v ? v->name : "";
+}
+
+int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_fit_occupancy: null handle");
+    const smoe::Variant* v = find_variant(h, num_blocks, false);
+    if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_fit_occupancy: no variant");
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SMOE_ERR_HIP, "hipSetDevice");
+    return v->fit_waves_per_cu(h->N, false);
 }
 
 int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const float* loss_w,

@@ -17,7 +17,7 @@ struct KernelConsts {
     float epsm;         // margin / 2^p                    smoe.py:931
     float scale;        // 1 / (2^p - 1)                   fake_quant nudged scale, smoe.py:899
     float inv_scale;    // 1 / scale
-    float nudged_max;   // (2^p - 1) * scale
+    float nudged_max;   // min(1, (2^p - 1) * scale): upper clamp of clip_by_value + fake quant
     float cw[SMOE_MAX_CHANNELS];  // per-channel loss weight / N   smoe.py:933-937
     float n_dis;        // sqrt((2 pi)^d)                  smoe.py:812
     int use_det;        // smoe.py:809
@@ -88,6 +88,7 @@ struct Variant {
     hipError_t (*fit)(const FitArgs&, hipStream_t);
     hipError_t (*fwd)(const FwdArgs&, hipStream_t);
     size_t (*lds_bytes)(int N, bool has_lw);
+    int (*fit_waves_per_cu)(int N, bool has_lw);
 };
 
 const Variant* variants(int* count);

@@ -101,13 +101,18 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 // ---------------------------------------------------------------------------
 // per-pixel forward (+ optional backward accumulation)
 // ---------------------------------------------------------------------------
+// sqrt(0.5 * log2(e)): with A' = SQ * A, |A'^T r|^2 = maha * 0.5*log2(e), so
+// exp(-maha/2) = exp2(-|z'|^2) and the per-kernel scale multiply disappears.
+#define SMOE_SQ 0.84932180028801904272f
+#define SMOE_INV_SQ 1.17740022503374817543f
+
 template <int D, int C, int K>
 struct BlockRegs {
     using Lt = Layout<D, C, K>;
     float P[Lt::LP_STRIDE];   // packed params + flags, filled from LDS
+    float As[K][Lt::TRI];     // A' = SQ * A (lower triangle)
+    float cz[K][D];           // c = A'^T mu, so z' = A'^T x - c
     float coef[K];            // pi * prod diag(A) / sqrt((2pi)^d), 0 when the kernel is inactive
-    float invpi[K];           // 1/pi (0 when inactive)
-    float invdiag[K][D];      // 1/A[l][l]
 
     __device__ __forceinline__ float pi(int k) const { return P[k * Lt::PK + Lt::O_PI]; }
     __device__ __forceinline__ float mu(int k, int l) const { return P[k * Lt::PK + Lt::O_MU + l]; }
@@ -116,6 +121,7 @@ struct BlockRegs {
     __device__ __forceinline__ float ga(int k, int l, int c) const { return P[k * Lt::PK + Lt::O_GA + l * C + c]; }
     __device__ __forceinline__ bool flag(int k) const { return P[Lt::LP_ACT + k] != 0.0f; }
     __device__ __forceinline__ bool frozen() const { return P[Lt::LP_FROZEN] != 0.0f; }
+    __device__ __forceinline__ bool act(int k) const { return flag(k) && (pi(k) > 0.0f); }
 
     __device__ __forceinline__ void load(const float* __restrict__ lds_block) {
         const float4* src = reinterpret_cast<const float4*>(lds_block);
@@ -130,140 +136,143 @@ struct BlockRegs {
     __device__ __forceinline__ void derive(const KernelConsts& kc) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool act = flag(k) && (pi(k) > 0.0f);
             float det = 1.0f;
 #pragma unroll
-            for (int l = 0; l < D; ++l) {
-                det *= A(k, l, l);
-                invdiag[k][l] = act ? fast_rcp(A(k, l, l)) : 0.0f;
-            }
+            for (int l = 0; l < D; ++l) det *= A(k, l, l);
             const float nq = kc.use_det ? det / kc.n_dis : 1.0f;   // n_quo = n_div / n_dis
-            coef[k] = act ? nq * pi(k) : 0.0f;
-            invpi[k] = act ? fast_rcp(pi(k)) : 0.0f;
+            coef[k] = act(k) ? nq * pi(k) : 0.0f;
+#pragma unroll
+            for (int l = 0; l < D; ++l)
+#pragma unroll
+                for (int m = 0; m <= l; ++m) As[k][tri_index(l, m)] = SMOE_SQ * A(k, l, m);
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float c = 0.0f;
+#pragma unroll
+                for (int l = m; l < D; ++l) c = fmaf(mu(k, l), As[k][tri_index(l, m)], c);
+                cz[k][m] = c;
+            }
+            if (!kc.train_gammas) {          // smoe.py:841-848: the slopes are not part of the graph
+#pragma unroll
+                for (int i = 0; i < D * C; ++i) P[k * Lt::PK + Lt::O_GA + i] = 0.0f;
+            }
         }
     }
 };
 
 template <int D, int C, int K>
 struct PixelOut {
-    float w[K];     // gate
     float wt[K];    // masked gate
     float q[C];     // quantised reconstruction
-    float y[C];     // pre-clip blend
 };
 
 // One pixel.  TRAIN: accumulate raw gradient sums into acc[] (layout = packed params,
-// "raw" meaning before the per-lane linear post-transform, see finish_partials).
+// "raw" meaning before the per-lane linear post-transform, see finish_partials):
+//   acc[pi_k]      += u_k                      u_k = dL/dlog g_k
+//   acc[mu_k,m]    += u_k z'_m                 z' = A'^T (x - mu)
+//   acc[A_k,l,m]   += u_k x_l z'_m             (x, not x - mu: corrected in finish_partials)
+//   acc[nu_k,c]    += wt_k G_c     acc[ga_k,l,c] += wt_k G_c x_l
+// The influence slot accumulates sum_n wt_k (> 0 iff some pixel passes the mask, smoe.py:829).
 template <int D, int C, int K, bool TRAIN>
 __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                       const float (&x)[D], const float (&t)[C], float lw,
                                       float* __restrict__ acc, PixelOut<D, C, K>& o) {
     using Lt = Layout<D, C, K>;
-    float r[K][D], z[K][D], g[K];
+    float z[K][D], g[K];
     float S = 0.0f;
-    // smoe.py:777-782,796,807: r = x - mu ; z = A^T r ; n = exp(-maha/2)
+    // smoe.py:777-782,796,807: z = A^T (x - mu) ; n = exp(-|z|^2 / 2)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float maha = 0.0f;
 #pragma unroll
-        for (int l = 0; l < D; ++l) r[k][l] = x[l] - R.mu(k, l);
-#pragma unroll
         for (int m = 0; m < D; ++m) {
-            float zz = r[k][m] * R.A(k, m, m);
+            float zz = -R.cz[k][m];
 #pragma unroll
-            for (int l = m + 1; l < D; ++l) zz = fmaf(r[k][l], R.A(k, l, m), zz);
+            for (int l = D - 1; l >= m; --l) zz = fmaf(x[l], R.As[k][tri_index(l, m)], zz);
             z[k][m] = zz;
-            maha = fmaf(zz, zz, maha);
+            maha = (m == 0) ? zz * zz : fmaf(zz, zz, maha);
         }
-        g[k] = R.coef[k] * fast_exp2(maha * -0.72134752044448170368f);   // exp(-maha/2)
-        S += g[k];
+        g[k] = R.coef[k] * fast_exp2(-maha);
+        S = (k == 0) ? g[k] : S + g[k];
     }
     // smoe.py:820-827: normalise, floor 1e-11, min-influence mask
-    const float Sm = fmaxf(S, 10e-12f);
-    const float inv = fast_rcp(Sm);
-    const bool passS = S > 10e-12f;
-    float e[K][C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) o.y[c] = 0.0f;
+    const float inv = fast_rcp(fmaxf(S, 10e-12f));
+    float w[K], e[K][C], y[C];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        o.w[k] = g[k] * inv;
-        const bool M = o.w[k] > kc.tau;
-        o.wt[k] = M ? o.w[k] : 0.0f;
-        if (TRAIN || true) acc[Lt::S_CNT + k] += M ? 1.0f : 0.0f;
+        w[k] = g[k] * inv;
+        o.wt[k] = (w[k] > kc.tau) ? w[k] : 0.0f;
+        acc[Lt::S_CNT + k] += o.wt[k];
         // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             float ee = R.nu(k, c);
-            if (kc.train_gammas) {
 #pragma unroll
-                for (int l = 0; l < D; ++l) ee = fmaf(R.ga(k, l, c), x[l], ee);
-            }
+            for (int l = 0; l < D; ++l) ee = fmaf(R.ga(k, l, c), x[l], ee);
             e[k][c] = ee;
-            o.y[c] = fmaf(o.wt[k], ee, o.y[c]);
+            y[c] = (k == 0) ? o.wt[k] * ee : fmaf(o.wt[k], ee, y[c]);
         }
     }
     // smoe.py:857,899 (clip + fake quant), 905-937 (mse / margin loss)
     float Gc[C];
+    float dot = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const float yc = fminf(fmaxf(o.y[c], 0.0f), 1.0f);
-        const float cl = fminf(yc, kc.nudged_max);
-        o.q[c] = floorf(fmaf(cl, kc.inv_scale, 0.5f)) * kc.scale;
+        // clip_by_value(0,1) then the fake-quant clamp to its nudged range: kc.nudged_max = min(1, nudged max)
+        const float yc = __builtin_amdgcn_fmed3f(y[c], 0.0f, kc.nudged_max);
+        o.q[c] = floorf(fmaf(yc, kc.inv_scale, 0.5f)) * kc.scale;
         const float diff = o.q[c] - t[c];
         const float ad = fabsf(diff) - kc.epsm;
         acc[Lt::S_SSE] = fmaf(diff, diff, acc[Lt::S_SSE]);
-        acc[Lt::S_LOSS] = fmaf(kc.cw[c] * lw, ad * ad, acc[Lt::S_LOSS]);
+        const float cwl = kc.cw[c] * lw;
+        acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
         if (TRAIN) {
-            const bool inside = (o.y[c] >= 0.0f) && (o.y[c] <= 1.0f);
-            const float sg = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
-            Gc[c] = inside ? (2.0f * kc.cw[c] * lw) * ad * sg : 0.0f;
+            // sign(diff) in {-1,0,1}: |diff| is either 0 or >= 2^-30, so diff * 2^100 saturates the clamp
+            const float sg = __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -1.0f, 1.0f);
+            const float gm = (cwl + cwl) * (ad * sg);
+            // clip_by_value / fake-quant straight-through: gradient only where neither clamp acted
+            Gc[c] = (yc == y[c]) ? gm : 0.0f;
+            dot = fmaf(Gc[c], y[c], dot);              // sum_k h_k w_k == sum_c G_c y_c
         }
     }
     if (!TRAIN) return;
     // ---- reverse pass, SURVEY Appendix A.4 (tf.gradients, smoe.py:1148) -------
-    float h[K];
-    float dot = 0.0f;
+    // u_k = w_k (h_k - dot) with h_k = M_k (e_k.G)  ==  wt_k (e_k.G) - w_k dot ;
+    // when the normaliser sits on its 1e-11 floor it is a constant and the dot term drops.
+    dot = (S > 10e-12f) ? dot : 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        float hh = 0.0f;
+        float eg = e[k][0] * Gc[0];
 #pragma unroll
-        for (int c = 0; c < C; ++c) hh = fmaf(e[k][c], Gc[c], hh);
-        h[k] = (o.wt[k] > 0.0f) ? hh : 0.0f;
-        dot = fmaf(h[k], o.w[k], dot);
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float u = passS ? o.w[k] * (h[k] - dot) : o.w[k] * h[k];
+        for (int c = 1; c < C; ++c) eg = fmaf(e[k][c], Gc[c], eg);
+        const float u = fmaf(o.wt[k], eg, -(w[k] * dot));
         float* a = acc + k * Lt::PK;
         a[Lt::O_PI] += u;
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             const float uz = u * z[k][m];
-            a[Lt::O_MU + m] += uz;                                   // sum u z_m   (-> A*(.) later)
+            a[Lt::O_MU + m] += uz;
 #pragma unroll
             for (int l = m; l < D; ++l)
-                a[Lt::O_A + tri_index(l, m)] = fmaf(r[k][l], uz, a[Lt::O_A + tri_index(l, m)]);
+                a[Lt::O_A + tri_index(l, m)] = fmaf(x[l], uz, a[Lt::O_A + tri_index(l, m)]);
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float wg = o.wt[k] * Gc[c];
             a[Lt::O_NU + c] += wg;
-            if (kc.train_gammas) {
 #pragma unroll
-                for (int l = 0; l < D; ++l)
-                    a[Lt::O_GA + l * C + c] = fmaf(wg, x[l], a[Lt::O_GA + l * C + c]);
-            }
+            for (int l = 0; l < D; ++l)
+                a[Lt::O_GA + l * C + c] = fmaf(wg, x[l], a[Lt::O_GA + l * C + c]);
         }
     }
 }
 
-// Per-lane linear post-transform of the raw partial sums into partial gradients
-// (all maps are linear in the sums and use block-uniform parameters, so they commute
-// with the cross-lane reduction):
+// Per-lane linear post-transform of the raw partial sums into partial gradients (all maps
+// are linear in the sums and use block-uniform parameters, so they commute with the
+// cross-lane reduction).  With suz'_m = sum u z'_m (z' = SQ z) and sxz'_lm = sum u x_l z'_m:
 //   d/dpi   = (sum u) / pi
-//   d/dmu_l = sum_m A[l][m] * (sum u z_m)                 (dm/dmu = -2 A z, dL/dm = -u/2)
-//   d/dA_lm = -(sum u r_l z_m) + [l==m, use_det] (sum u)/A_ll
+//   d/dmu_l = sum_m A[l][m] suz_m                        (dm/dmu = -2 A z, dL/dm = -u/2)
+//   d/dA_lm = -(sxz_lm - mu_l suz_m) + [l==m, use_det] (sum u)/A_ll
 template <int D, int C, int K>
 __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                                 float* __restrict__ acc) {
@@ -271,10 +280,11 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float* a = acc + k * Lt::PK;
+        const bool act = R.act(k);
         const float su = a[Lt::O_PI];
         float suz[D];
 #pragma unroll
-        for (int m = 0; m < D; ++m) suz[m] = a[Lt::O_MU + m];
+        for (int m = 0; m < D; ++m) suz[m] = a[Lt::O_MU + m] * SMOE_INV_SQ;
 #pragma unroll
         for (int l = 0; l < D; ++l) {
             float gm = 0.0f;
@@ -286,12 +296,12 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
         for (int l = 0; l < D; ++l) {
 #pragma unroll
             for (int m = 0; m <= l; ++m) {
-                float v = -a[Lt::O_A + tri_index(l, m)];
-                if (l == m && kc.use_det) v = fmaf(su, R.invdiag[k][l], v);
+                float v = fmaf(R.mu(k, l), suz[m], -(a[Lt::O_A + tri_index(l, m)] * SMOE_INV_SQ));
+                if (l == m && kc.use_det) v = fmaf(su, act ? fast_rcp(R.A(k, l, l)) : 0.0f, v);
                 a[Lt::O_A + tri_index(l, m)] = v;
             }
         }
-        a[Lt::O_PI] = su * R.invpi[k];
+        a[Lt::O_PI] = su * (act ? fast_rcp(R.pi(k)) : 0.0f);
     }
 }
 
@@ -303,16 +313,18 @@ struct Tile {
     using Lt = Layout<D, C, K>;
     static constexpr int BPW = 64 / G;                  // blocks per wavefront
     static constexpr int NB = WAVES * BPW;              // blocks per workgroup
-    static constexpr int CH = (G >= 32) ? G : 32;       // slots reduced per pass
+    static constexpr int CH = (G == 16) ? 16 : 32;      // slots reduced per pass
     static constexpr int ROW = 64 + 4;                  // padded row (bank-conflict-free b128 reads)
     static constexpr int NCHUNK = (Lt::NSLOT + CH - 1) / CH;
     static constexpr int SPL = (Lt::NSLOT + G - 1) / G; // owned slots per lane
     static constexpr int THREADS = WAVES * 64;
+    static constexpr int MV_STRIDE = round_up(2 * Lt::NPAR, 4);   // Adam m,v image of one block
 
     // float offsets inside dynamic LDS
     __host__ __device__ static int off_coords() { return 0; }
     __host__ __device__ static int off_par(int N) { return round_up(D * N, 4); }
-    __host__ __device__ static int off_scratch(int N) { return off_par(N) + NB * Lt::LP_STRIDE; }
+    __host__ __device__ static int off_mv(int N) { return off_par(N) + NB * Lt::LP_STRIDE; }
+    __host__ __device__ static int off_scratch(int N) { return off_mv(N) + NB * MV_STRIDE; }
     __host__ __device__ static int off_tgt(int N) { return off_scratch(N) + WAVES * CH * ROW; }
     __host__ __device__ static int off_lw(int N) { return off_tgt(N) + NB * C * N; }
     __host__ __device__ static size_t bytes(int N, bool has_lw) {
@@ -346,9 +358,12 @@ __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, c
     }
 }
 
-// Cross-lane reduction of acc[0..NSLOT) over the G lanes of a block; lane `sub` ends up
-// with the totals of slots sub, sub+G, ... in total[].
-template <int D, int C, int K, int G, int WAVES>
+// Cross-lane reduction of acc[FIRST..NSLOT) over the G lanes of a block through an LDS
+// transpose: lane `sub` ends up with the totals of its slots sub, sub+G, ... in total[].
+// Pass c moves slots [c*CH, (c+1)*CH): every lane stores its partials of these slots as
+// rows (conflict-free 4-byte stores), then the owner of each row sums its G entries with
+// 16-byte reads (rows are padded by 4 floats so the b128 reads do not conflict).
+template <int D, int C, int K, int G, int WAVES, int FIRST>
 __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, float* __restrict__ scratch_wave,
                                              int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
     using T = Tile<D, C, K, G, WAVES>;
@@ -359,26 +374,31 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
     for (int s = 0; s < T::SPL; ++s) total[s] = 0.0f;
 #pragma unroll
     for (int c = 0; c < T::NCHUNK; ++c) {
+        if ((c + 1) * T::CH <= FIRST) continue;            // compile-time: nothing wanted in this pass
 #pragma unroll
         for (int a = 0; a < T::CH; ++a) {
-            if (c * T::CH + a < Lt::NSLOT) scratch_wave[a * T::ROW + lane] = acc[c * T::CH + a];
+            const int j = c * T::CH + a;
+            if (j >= FIRST && j < Lt::NSLOT) scratch_wave[a * T::ROW + lane] = acc[j];
         }
         wave_lds_sync();
+        {
+            constexpr int dummy = 0; (void)dummy;
+            const int s = (c * T::CH) / G;                  // which of the lane's slots lives in this pass
+            const int h = c - s * (G / T::CH);              // which CH-wide group of lanes owns rows now
+            const int a = sub - h * T::CH;
+            const int j = c * T::CH + a;
+            if (a >= 0 && a < T::CH && j >= FIRST && j < Lt::NSLOT) {
+                const float4* row = reinterpret_cast<const float4*>(scratch_wave + a * T::ROW + grp * G);
+                float4 sum = row[0];
 #pragma unroll
-        for (int s = 0; s < T::SPL; ++s) {
-            if ((s * G) / T::CH == c) {            // compile-time: which pass holds this lane's s-th slot
-                const int j = sub + s * G;
-                if (j < Lt::NSLOT) {
-                    const int a = j - c * T::CH;
-                    const float4* row = reinterpret_cast<const float4*>(scratch_wave + a * T::ROW + grp * G);
-                    float4 sum = row[0];
-#pragma unroll
-                    for (int i = 1; i < G / 4; ++i) {
-                        const float4 q = row[i];
-                        sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
-                    }
-                    total[s] = (sum.x + sum.y) + (sum.z + sum.w);
+                for (int i = 1; i < G / 4; ++i) {
+                    const float4 q = row[i];
+                    sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
                 }
+                const float tot = (sum.x + sum.y) + (sum.z + sum.w);
+#pragma unroll
+                for (int ss = 0; ss < T::SPL; ++ss)
+                    if (ss == s) total[ss] = tot;
             }
         }
         wave_lds_sync();
@@ -388,6 +408,28 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
 // ---------------------------------------------------------------------------
 // fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
 // ---------------------------------------------------------------------------
+template <int D, int C, int K, bool HAS_LW>
+__device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
+                                                 const float* __restrict__ s_coords, const float* __restrict__ s_tgt,
+                                                 const float* __restrict__ s_lw, int N, int G, int sub,
+                                                 float* __restrict__ acc) {
+    const int pxl = (N + G - 1) / G;
+#pragma unroll 2
+    for (int i = 0; i < pxl; ++i) {
+        const int n = i * G + sub;
+        if (n < N) {
+            float x[D], t[C];
+#pragma unroll
+            for (int l = 0; l < D; ++l) x[l] = s_coords[l * N + n];
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+            const float lw = HAS_LW ? s_lw[n] : 1.0f;
+            PixelOut<D, C, K> o;
+            pixel<D, C, K, true>(R, kc, x, t, lw, acc, o);
+        }
+    }
+}
+
 template <int D, int C, int K, int G, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
@@ -407,6 +449,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 
     float* s_coords = lds + T::off_coords();
     float* s_par = lds + T::off_par(N) + lb * Lt::LP_STRIDE;
+    float* s_mv = lds + T::off_mv(N) + lb * T::MV_STRIDE;
     float* s_scratch = lds + T::off_scratch(N) + wave * (T::CH * T::ROW);
     const float* s_tgt = lds + T::off_tgt(N) + lb * (C * N);
     const float* s_lw = lds + T::off_lw(N) + lb * N;
@@ -415,28 +458,26 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
 
     // ---- owner set-up: this lane owns packed slots sub, sub+G, ... of its block --------
-    float pv[T::SPL], mv[T::SPL], vv[T::SPL], lr[T::SPL], reg[T::SPL];
-    long goff[T::SPL];
-    int gtensor[T::SPL], gkern[T::SPL];
+    // per-slot learning rate (0 = not trained) and l1 regulariser constant stay in registers;
+    // the parameter and its Adam slots live in LDS between iterations.
+    float lr[T::SPL], reg[T::SPL];
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
         const int j = sub + s * G;
-        pv[s] = mv[s] = vv[s] = lr[s] = reg[s] = 0.0f;
-        goff[s] = 0; gtensor[s] = -1; gkern[s] = 0;
+        lr[s] = reg[s] = 0.0f;
         if (j < Lt::NPAR) {
             int tensor, kern; long off;
             decode_slot<D, C, K>(j, b, tensor, off, kern);
-            gtensor[s] = tensor; goff[s] = off; gkern[s] = kern;
-            pv[s] = pick(a.p, tensor)[off];
-            mv[s] = pick(a.m, tensor)[off];
-            vv[s] = pick(a.v, tensor)[off];
+            s_par[j] = pick(a.p, tensor)[off];
+            s_mv[2 * j] = pick(a.m, tensor)[off];
+            s_mv[2 * j + 1] = pick(a.v, tensor)[off];
             // optimizer groups, smoe.py:1102-1104; untrainable variables dropped, 1112-1117
-            lr[s] = (tensor == 0) ? a.lr_pis : ((tensor == 2 || tensor == 3) ? a.lr_steer : a.lr_expert);
-            if (tensor == 0 && !a.train_pis) lr[s] = 0.0f;
-            if (tensor == 1 && !a.train_musx) lr[s] = 0.0f;
-            if (tensor == 4 && !a.kc.train_gammas) lr[s] = 0.0f;
+            float r = (tensor == 0) ? a.lr_pis : ((tensor == 2 || tensor == 3) ? a.lr_steer : a.lr_expert);
+            if (tensor == 0 && !a.train_pis) r = 0.0f;
+            if (tensor == 1 && !a.train_musx) r = 0.0f;
+            if (tensor == 4 && !a.kc.train_gammas) r = 0.0f;
+            lr[s] = r;
             reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? a.reg_u : 0.0f);   // smoe.py:1027,1044
-            s_par[j] = pv[s];
         } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
             const int k = j - Lt::S_CNT;
             s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
@@ -445,116 +486,122 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         }
     }
     const float loss0 = (a.loss0 != nullptr) ? a.loss0[b] : 0.0f;
+    const bool has_loss0 = a.loss0 != nullptr;
+    const bool has_reg = (a.reg_pi != 0.0f) || (a.reg_u != 0.0f);
     float last_loss = 0.0f, last_sse = 0.0f;
     __syncthreads();
 
     float b1p = a.b1p, b2p = a.b2p;
-    BlockRegs<D, C, K> R;
-    const int pxl = (N + G - 1) / G;
+    const KernelConsts kc = a.kc;
+    const float beta1 = a.beta1, beta2 = a.beta2, adam_eps = a.eps, clip = a.clip;
+    const float reg_pi = a.reg_pi, reg_u = a.reg_u;
 
     for (int it = 0; it < a.n_iters; ++it) {
-        R.load(s_par);
-        R.derive(a.kc);
-        const bool frozen = R.frozen();
-
         float acc[Lt::NSLOT];
 #pragma unroll
         for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
-
-        for (int i = 0; i < pxl; ++i) {
-            const int n = i * G + sub;
-            if (n < N) {
-                float x[D], t[C];
+        bool frozen;
+        float reg_loss = 0.0f;
+        {
+            BlockRegs<D, C, K> R;
+            R.load(s_par);
+            R.derive(kc);
+            frozen = R.frozen();
+            if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
 #pragma unroll
-                for (int l = 0; l < D; ++l) x[l] = s_coords[l * N + n];
+                for (int k = 0; k < K; ++k) {
+                    if (R.act(k)) {
+                        reg_loss += reg_pi * R.pi(k);
 #pragma unroll
-                for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
-                const float lw = has_lw ? s_lw[n] : 1.0f;
-                PixelOut<D, C, K> o;
-                pixel<D, C, K, true>(R, a.kc, x, t, lw, acc, o);
+                        for (int l = 0; l < D; ++l) reg_loss += reg_u * R.A(k, l, l);
+                    }
+                }
             }
+            if (has_lw) pixel_loop_train<D, C, K, true>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+            else pixel_loop_train<D, C, K, false>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
         }
-        finish_partials<D, C, K>(R, a.kc, acc);
+        {
+            BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
+            R2.load(s_par);
+            finish_partials<D, C, K>(R2, kc, acc);
+        }
 
         float total[T::SPL];
-        reduce_slots<D, C, K, G, WAVES>(acc, s_scratch, lane, total);
+        reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
 
         // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
         const float one_m_b1p = 1.0f - b1p;
         const float sq = sqrtf(1.0f - b2p);
+        float newp[T::SPL];
+        bool bad = false;
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = sub + s * G;
-            if (j < Lt::NPAR) {
-                if (lr[s] != 0.0f && !frozen) {
-                    float gsum = total[s];
-                    if (reg[s] != 0.0f) {
-                        const int k = gkern[s];
-                        const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (s_par[k * Lt::PK + Lt::O_PI] > 0.0f);
-                        if (act) gsum += reg[s];
-                    }
-                    if (a.clip > 0.0f) gsum = fminf(fmaxf(gsum, -a.clip), a.clip);
-                    const float alpha = lr[s] * sq / one_m_b1p;
-                    mv[s] = mv[s] + (gsum - mv[s]) * (1.0f - a.beta1);
-                    vv[s] = vv[s] + (gsum * gsum - vv[s]) * (1.0f - a.beta2);
-                    pv[s] = pv[s] - (mv[s] * alpha) / (sqrtf(vv[s]) + a.eps);
-                }
-            } else if (j == Lt::S_LOSS) {
-                float lossv = total[s];
-                if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const bool act = R.flag(k) && (R.pi(k) > 0.0f);
-                        if (act) {
-                            lossv += a.reg_pi * R.pi(k);
-#pragma unroll
-                            for (int l = 0; l < D; ++l) lossv += a.reg_u * R.A(k, l, l);
-                        }
-                    }
-                }
-                if (!frozen) {
-                    last_loss = lossv;
-                    const bool bad = (lossv != lossv) ||
-                                     (a.loss0 != nullptr && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f));
-                    if (bad) s_par[Lt::LP_FROZEN] = 1.0f;     // takes effect from the next iteration
-                }
-            } else if (j == Lt::S_SSE) {
-                if (!frozen) last_sse = total[s];
+            const int jc = (j < Lt::NPAR) ? j : 0;
+            const float pv = s_par[jc];
+            const float mv = s_mv[2 * jc];
+            const float vv = s_mv[2 * jc + 1];
+            float gsum = total[s];
+            if (has_reg && reg[s] != 0.0f) {
+                const int k = jc / Lt::PK;
+                const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (s_par[k * Lt::PK + Lt::O_PI] > 0.0f);
+                gsum += act ? reg[s] : 0.0f;
             }
+            if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
+            const float alpha = lr[s] * sq / one_m_b1p;
+            const float m2 = mv + (gsum - mv) * (1.0f - beta1);
+            const float v2 = vv + (gsum * gsum - vv) * (1.0f - beta2);
+            const float p2 = pv - (m2 * alpha) / (sqrtf(v2) + adam_eps);
+            const bool upd = (j < Lt::NPAR) && (lr[s] != 0.0f) && !frozen;
+            newp[s] = upd ? p2 : pv;
+            if (upd) { s_mv[2 * jc] = m2; s_mv[2 * jc + 1] = v2; }
+            if (j == Lt::S_LOSS && !frozen) {
+                const float lossv = total[s] + reg_loss;
+                last_loss = lossv;
+                bad = (lossv != lossv) || (has_loss0 && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f));
+            }
+            if (j == Lt::S_SSE && !frozen) last_sse = total[s];
         }
         wave_lds_sync();   // every lane has consumed the old flags / params
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = sub + s * G;
             if (j < Lt::NPAR) {
-                s_par[j] = pv[s];
+                s_par[j] = newp[s];
             } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
                 if (!frozen) s_par[Lt::LP_ACT + (j - Lt::S_CNT)] = (total[s] > 0.0f) ? 1.0f : 0.0f;
+            } else if (j == Lt::S_LOSS) {
+                if (bad) s_par[Lt::LP_FROZEN] = 1.0f;      // takes effect from the next iteration
             }
         }
         wave_lds_sync();
-        b1p *= a.beta1;
-        b2p *= a.beta2;
+        b1p *= beta1;
+        b2p *= beta2;
     }
 
-    // ---- write back -----------------------------------------------------------
+    // ---- write back (pointers are re-read from the kernarg segment: keeping 18 of them
+    // live across the iteration loop costs SGPR spills inside it) ------------------------
+    const FitArgs* ka = (const FitArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
     if (valid_b) {
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = sub + s * G;
             if (j < Lt::NPAR) {
-                pick(a.p, gtensor[s])[goff[s]] = pv[s];
-                pick(a.m, gtensor[s])[goff[s]] = mv[s];
-                pick(a.v, gtensor[s])[goff[s]] = vv[s];
+                int tensor, kern; long off;
+                decode_slot<D, C, K>(j, b, tensor, off, kern);
+                pick(ka->p, tensor)[off] = s_par[j];
+                pick(ka->m, tensor)[off] = s_mv[2 * j];
+                pick(ka->v, tensor)[off] = s_mv[2 * j + 1];
             } else if (j == Lt::S_LOSS) {
-                if (a.loss_out != nullptr && a.n_iters > 0) a.loss_out[b] = last_loss;
-                if (a.diverged != nullptr) a.diverged[b] = (s_par[Lt::LP_FROZEN] != 0.0f) ? 1u : 0u;
+                if (ka->loss_out != nullptr && ka->n_iters > 0) ka->loss_out[b] = last_loss;
+                if (ka->diverged != nullptr) ka->diverged[b] = (s_par[Lt::LP_FROZEN] != 0.0f) ? 1u : 0u;
                 uint32_t mask = 0u;
 #pragma unroll
                 for (int k = 0; k < K; ++k) mask |= (s_par[Lt::LP_ACT + k] != 0.0f) ? (1u << k) : 0u;
-                a.active[b] = mask;
+                ka->active[b] = mask;
             } else if (j == Lt::S_SSE) {
-                if (a.sse_out != nullptr && a.n_iters > 0) a.sse_out[b] = last_sse;
+                if (ka->sse_out != nullptr && ka->n_iters > 0) ka->sse_out[b] = last_sse;
             }
         }
     }
@@ -650,7 +697,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     }
 
     float total[T::SPL];
-    reduce_slots<D, C, K, G, WAVES>(acc, s_scratch, lane, total);
+    reduce_slots<D, C, K, G, WAVES, Layout<D, C, K>::NPAR>(acc, s_scratch, lane, total);
 
     // publish the influence flags of the block through LDS (needed by every lane below)
 #pragma unroll
@@ -672,7 +719,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
                 if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        const bool act = R.flag(k) && (R.pi(k) > 0.0f);
+                        const bool act = R.act(k);
                         if (act) {
                             lossv += a.reg_pi * R.pi(k);
 #pragma unroll
@@ -813,8 +860,19 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
 template <int D, int C, int K, int G, int WAVES>
 size_t lds_bytes(int N, bool has_lw) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw); }
 
+template <int D, int C, int K, int G, int WAVES>
+int fit_occupancy(int N, bool has_lw) {
+    using T = Tile<D, C, K, G, WAVES>;
+    int nb = 0;
+    auto kern = fit_kernel<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(N, has_lw);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, shm) != hipSuccess) return -1;
+    return nb * WAVES;       // resident wavefronts per CU
+}
+
 #define SMOE_VARIANT(D, C, K, G, W) \
-    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W> }
+    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W> }
 
 static const Variant g_variants[] = {
     SMOE_VARIANT(2, 1, 4, 16, 4), SMOE_VARIANT(2, 1, 4, 64, 2),

@@ -161,6 +161,9 @@ class BlockEngine:
     def set_tiling(self, lanes_per_block: int):
         _lib.check(self.lib.smoe_set_tiling(self._h, lanes_per_block))
 
+    def fit_occupancy(self, B: int) -> int:
+        return int(self.lib.smoe_fit_occupancy(self._h, B))
+
     def fit_variant(self, B: int) -> str:
         return self.lib.smoe_fit_variant(self._h, B).decode()
 
