@@ -442,30 +442,3 @@ def fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int = 100,
 def psnr_from_sse(sse_total: float, n_values: int) -> float:
     """plotter.py:14-15 with mse_op of smoe.py:1053: 10*log10((2^p)^2 / (mean(diff^2)*(2^p)^2))."""
     return float(-10.0 * np.log10(sse_total / n_values))
-
-
-# --------------------------------------------------------------------------
-# deterministic synthetic blocks (SURVEY section 8(d))
-# --------------------------------------------------------------------------
-def synthetic_blocks(B: int, block_shape: Sequence[int], C: int, seed: int) -> np.ndarray:
-    """Random oriented step edge + linear ramp + noise, rounded to uint8 and /255
-    (mirrors utils.py:126-128).  Returns (B, *block_shape, C) float32."""
-    rng = np.random.default_rng(seed)
-    d = len(block_shape)
-    axes = [np.linspace(0, 1, s) for s in block_shape]
-    grids = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1)          # (*shape, d)
-    normal = rng.normal(size=(B, d))
-    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
-    offset = rng.uniform(0.25, 0.75, size=(B,))
-    lo = rng.uniform(0.1, 0.9, size=(B, C))
-    hi = rng.uniform(0.1, 0.9, size=(B, C))
-    slope = rng.uniform(-0.3, 0.3, size=(B, d, C))
-    g = grids.reshape((1,) + grids.shape)
-    proj = np.einsum("b...l,bl->b...", np.broadcast_to(g, (B,) + grids.shape) - 0.5, normal) + 0.5
-    side = (proj > offset.reshape((B,) + (1,) * d)).astype(np.float64)
-    ex = (B,) + (1,) * d + (C,)
-    img = lo.reshape(ex) * (1 - side[..., None]) + hi.reshape(ex) * side[..., None]
-    img = img + np.einsum("...l,blc->b...c", grids - 0.5, slope)
-    img = img + rng.normal(scale=2 / 255, size=img.shape)
-    img = np.clip(img, 0, 1)
-    return (np.round(img * 255).astype(np.uint8).astype(np.float32) / np.float32(255.))

@@ -3,6 +3,7 @@ R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R,'tests'))
 import numpy as np, torch
 from oracle import smoe_oracle as o
+from steered_mixture_of_experts_amd.blocks import synthetic_blocks
 from test_gpu_parity import _setup, _engine, _to_dev, _to_host, _planar, _mask_to_bits, SHAPES
 np.set_printoptions(precision=2, linewidth=220)
 for (shape, C, kpd, yuv) in SHAPES[:2]:

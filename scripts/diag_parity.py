@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np, torch
 from oracle import smoe_oracle as o
+from steered_mixture_of_experts_amd.blocks import synthetic_blocks
 from test_gpu_parity import _setup, _engine, _to_dev, _to_host, _planar, _mask_to_bits, SHAPES
 
 for (shape, C, kpd, yuv) in SHAPES:

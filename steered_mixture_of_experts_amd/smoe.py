@@ -1,0 +1,454 @@
+"""``Smoe`` -- host-side mirror of the reference's model facade (reference smoe.py:37-2578)
+for the per-block hot path, backed by the HIP kernels in libsmoe_hip.so.
+
+Same entry points, argument names and parameter-dict layout as the reference
+(``Smoe(image, kernels_per_dim, ...)``, ``set_optimizer``, ``train``, ``run_batched``,
+``get_params`` / ``get_best_params``, ``get_reconstruction`` ...), with block-independent
+semantics: ``batch_size`` is the block shape, ``kernels_per_dim`` the kernels per block per
+axis, and every block is its own model (own [0,1]^d domain, own K kernels, own Adam state) --
+``get_params()[name][b]`` is what the reference's ``Smoe(block_b, ...).get_params()[name]``
+returns.  All blocks are fitted by ONE kernel launch per chunk of iterations instead of one
+``session.run`` per block per iteration (smoe.py:1643-1702).
+
+Not rebuilt here (SURVEY section 2 "OUT OF SCOPE" / section 8(f) "next"): shared global
+kernels with batch overlap, quantisation-aware fitting, SSIM loss, support vectors, motion
+models, kernel adding.  Passing those options raises NotImplementedError instead of silently
+doing something else.
+"""
+from __future__ import annotations
+
+import pickle
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import blocks as blk
+from . import dist as sdist
+from .engine import PARAM_NAMES, EngineConfig
+
+
+class Adam:
+    """Optimizer configuration object standing in for ``tf.train.AdamOptimizer`` (the
+    reference only reads ``_lr`` before handing the object to TF, smoe.py:1120-1144)."""
+
+    def __init__(self, learning_rate: float = 0.001, beta1: float = 0.9, beta2: float = 0.999,
+                 epsilon: float = 1e-8):
+        self._lr = float(learning_rate)
+        self._beta1 = float(beta1)
+        self._beta2 = float(beta2)
+        self._epsilon = float(epsilon)
+
+
+def _default_engine_factory(cfg: EngineConfig, device):
+    from .engine import BlockEngine          # loads libsmoe_hip.so; fails loudly if absent
+    return BlockEngine(cfg, device)
+
+
+class Smoe:
+    def __init__(self, image, kernels_per_dim=None, train_pis=True, init_params=None, start_batches=1,
+                 batch_size=None, train_gammas=True, train_musx=True, use_diff_center=False, radial_as=False,
+                 use_determinant=False, normalize_pis=True, quantization_mode=0, bit_depths=None,
+                 quantize_pis=False, lower_bounds=None, upper_bounds=None, use_yuv=True, only_y_gamma=False,
+                 ssim_opt=False, precision=8, add_kernel_slots=0, iter_offset=0, margin=0.5,
+                 overlap_of_batches=0, kernel_count_as_norm_l1=False, train_svs=False, affines=None,
+                 train_trafo=False, num_params_model=6, train_inverse_cov=False, init_flag=1,
+                 only_rec_from_checkpoint=False, loss_mask=None, device=None, engine_factory=None):
+        # -- options outside the hot path: refuse loudly ---------------------------------
+        unsupported = {
+            "use_diff_center": use_diff_center, "radial_as": radial_as, "ssim_opt": ssim_opt,
+            "train_svs": train_svs, "train_trafo": train_trafo, "train_inverse_cov": train_inverse_cov,
+            "only_y_gamma": only_y_gamma, "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
+        }
+        for name, val in unsupported.items():
+            if val:
+                raise NotImplementedError(f"Smoe({name}=True) is outside the per-block hot path (SURVEY section 8)")
+        if quantization_mode != 0 or quantize_pis:
+            raise NotImplementedError("quantisation-aware fitting is a 'next' row (SURVEY 8(f-3))")
+        if add_kernel_slots:
+            raise NotImplementedError("progressive kernel adding changes K over time; not part of the hot path")
+        if overlap_of_batches:
+            raise NotImplementedError("overlapping batches belong to the shared-kernel mode (SURVEY 8(f-1))")
+        if affines is not None:
+            raise NotImplementedError("per-frame motion models are out of scope")
+        assert kernels_per_dim is not None or init_params is not None, \
+            "You need to specify the kernel grid size or give initial parameters."   # smoe.py:249-250
+
+        image = np.asarray(image, dtype=np.float32)
+        self.image = image
+        self.dim_domain = image.ndim - 1                                # smoe.py:227
+        self.num_pixel = int(np.prod(image.shape[:self.dim_domain]))    # smoe.py:228
+        self.precision = precision
+        self.use_yuv = bool(use_yuv) and image.shape[-1] == 3           # smoe_test.py:41-44
+        self.only_y_gamma = only_y_gamma
+        self.ssim_opt = ssim_opt
+        self.use_diff_center = use_diff_center
+        self.radial_as = radial_as
+        self.use_determinant = use_determinant
+        self.quantization_mode = quantization_mode
+        self.quantize_pis = quantize_pis
+        self.bit_depths = bit_depths
+        self.lower_bounds = lower_bounds
+        self.upper_bounds = upper_bounds
+        self.train_pis, self.train_gammas, self.train_musx = train_pis, train_gammas, train_musx
+        self.train_inverse_cov = train_inverse_cov
+        self.train_trafo = train_trafo
+        self.affines = affines
+        self.margin = margin
+        self.overlap = overlap_of_batches
+        self.add_kernel_slots = 0
+        self.loss_mask = loss_mask
+        self.qparams = None
+        self.rparams = None
+
+        # -- block shape (smoe.py:231-247) -----------------------------------------------
+        d = self.dim_domain
+        if batch_size is None or batch_size[0] is None:
+            bs = tuple(image.shape[:d])                 # one block = the whole (small) image
+        elif len(batch_size) == d:
+            bs = tuple(int(b) for b in batch_size)
+        elif len(batch_size) == 1:
+            bs = tuple(int(batch_size[0]) for _ in range(d))
+        else:
+            raise ValueError("Required BatchSize doesn't fit to input dimension")    # smoe.py:237
+        self.batch_size_valued = bs
+        self.batch_size = bs
+        self.grid = blk.grid_shape(image.shape[:d], bs)
+        self.num_blocks = int(np.prod(self.grid))
+        self.start_batches = self.num_blocks                             # smoe.py:247
+        self.padded = blk.padded_shape(image.shape[:d], bs) != tuple(image.shape[:d])
+
+        # -- shard the independent blocks over ranks ------------------------
+        self.rank, self.world_size = sdist.world()
+        self.lo, self.hi = sdist.shard_range(self.num_blocks, self.rank, self.world_size)
+        all_blocks, valid = blk.image_to_blocks(image, bs)
+        blocks_local = all_blocks[self.lo:self.hi]
+        self.B = blocks_local.shape[0]
+        N = int(np.prod(bs))
+        self.N = N
+        C = image.shape[-1]
+        self.channels = C
+
+        # -- initial parameters (smoe.py:252-262) ----------------------------------------
+        if init_params:
+            p0 = {k: np.asarray(init_params[k], dtype=np.float32) for k in PARAM_NAMES}
+            if p0["pis"].ndim == 1:                       # a single block's dict: broadcast
+                p0 = {k: np.broadcast_to(v, (self.num_blocks,) + v.shape).copy() for k, v in p0.items()}
+            if p0["pis"].shape[0] != self.num_blocks:
+                raise ValueError("init_params must carry one parameter set per block")
+            p0 = {k: np.ascontiguousarray(v[self.lo:self.hi]) for k, v in p0.items()}
+            K = p0["pis"].shape[1]
+            self.musX_init = p0["musX"]
+        else:
+            kpd = list(kernels_per_dim)
+            if len(kpd) == 1:
+                kpd = kpd * d
+            p0 = blk.init_block_params(blocks_local, kpd, normalize_pis, train_inverse_cov)
+            K = p0["pis"].shape[1]
+            self.musX_init = blk.gen_domain_grid(kpd, d)
+        self.kernels = K
+        self.start_pis = K                                               # smoe.py:264, per block
+        self.kernel_count = K * self.num_blocks
+
+        # -- device state ---------------------------------------------------------------
+        self._engine_factory = engine_factory or _default_engine_factory
+        self._device = device
+        self._engine = None
+        self._engine_key = None
+        self.optimizer1 = self.optimizer2 = self.optimizer3 = None
+        self.grad_clip_value_abs = None
+        self._make_engine(pis_l1=0.0, u_l1=0.0)
+        dev = self._engine.device
+        self._target = torch.from_numpy(blk.to_planar(blocks_local)).to(dev)
+        lw = None
+        if self.padded:
+            lw = valid[self.lo:self.hi]
+        if loss_mask is not None:                                        # smoe.py:1674-1677
+            lm, _ = blk.image_to_blocks(np.asarray(loss_mask, dtype=np.float32)[..., None], bs)
+            lm = lm.reshape(self.num_blocks, N)[self.lo:self.hi]
+            lw = lm if lw is None else lw * lm
+        self._use_loss_mask_default = loss_mask is not None
+        self._valid = None if not self.padded else torch.from_numpy(np.ascontiguousarray(valid[self.lo:self.hi])).to(dev)
+        self._loss_w = None if lw is None else torch.from_numpy(np.ascontiguousarray(lw, dtype=np.float32)).to(dev)
+        self._params = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in p0.items()}
+        self._best = {k: v.clone() for k, v in self._params.items()}      # smoe.py:861-866
+        self._state = self._engine.new_adam_state(self._params)
+        self._active = torch.full((self.B,), (1 << K) - 1, dtype=torch.int32, device=dev)   # smoe.py:315
+        self._diverged = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+        self._loss0 = None
+        self._best_loss_blocks = None
+
+        # -- histories (smoe.py:183-199) -------------------------------------------------
+        self.losses, self.mses, self.num_pis, self.num_svs = [], [], [], []
+        self.qlosses, self.qmses = [], []
+        self.losses_history, self.mses_history = [], []
+        self.best_loss = None
+        self.best_mse = []
+        self.iter = iter_offset
+        self.valid = False
+        self.reconstruction_image = None
+        self.weight_matrix_argmax = None
+        self.weight_matrix = None
+
+    # ------------------------------------------------------------------------------------
+    def _make_engine(self, pis_l1: float, u_l1: float):
+        o1, o2, o3 = self.optimizer1, self.optimizer2, self.optimizer3
+        cfg = EngineConfig(
+            block_shape=self.batch_size_valued, channels=self.image.shape[-1], kernels=self.kernels,
+            precision=self.precision, margin=self.margin, use_determinant=bool(self.use_determinant),
+            use_yuv=bool(self.use_yuv), train_pis=bool(self.train_pis), train_gammas=bool(self.train_gammas),
+            train_musx=bool(self.train_musx),
+            lr_expert=o1._lr if o1 else 0.0, lr_pis=o2._lr if o2 else 0.0, lr_steer=o3._lr if o3 else 0.0,
+            beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999,
+            adam_eps=o1._epsilon if o1 else 1e-8,
+            grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
+            start_pis=self.kernels)
+        key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
+        key = repr(key)
+        if key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = self._engine_factory(cfg, self._device)
+            self._engine_key = key
+
+    @property
+    def kernel_list_per_batch(self) -> List[np.ndarray]:
+        """Per-block boolean kernel lists (smoe.py:315,1763-1766), local blocks only."""
+        bits = self._active.cpu().numpy().view(np.uint32)
+        K = self.kernels
+        mask = ((bits[:, None] >> np.arange(K, dtype=np.uint32)[None, :]) & 1).astype(bool)
+        return [m for m in mask]
+
+    # -- optimizer (smoe.py:1079-1204) ----------------------------------------------------
+    def set_optimizer(self, optimizer1, optimizer2=None, optimizer3=None, optimizer4=None, optimizer5=None,
+                      grad_clip_value_abs=None):
+        self.optimizer1 = optimizer1
+        self.optimizer2 = optimizer1 if optimizer2 is None else optimizer2
+        self.optimizer3 = optimizer1 if optimizer3 is None else optimizer3
+        self.grad_clip_value_abs = grad_clip_value_abs
+        # a fresh set of optimizers means fresh slots and beta powers, as in TF
+        self._make_engine(0.0, 0.0)
+        self._state = self._engine.new_adam_state(self._params)
+
+    # -- passes ----------------------------------------------------------------------------
+    def _global(self, loss, sse):
+        s = self._engine.reduce_scalars(loss, sse, None)
+        npi = (self._params["pis"] > 0).sum().to(torch.float64)
+        s[2] = npi
+        sdist.allreduce_sum_(s)
+        s = s.cpu().numpy()
+        total_px = float(self.num_blocks) * self.N
+        loss_val = s[0] / total_px                                   # smoe.py:1758
+        mse_val = s[1] / (total_px * self.channels) * (2 ** self.precision) ** 2   # smoe.py:1053,1759
+        return float(loss_val), float(mse_val), int(s[2])
+
+    def run_batched(self, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, train=True, update_reconstruction=False,
+                    with_quantized_params=False, sampling_percentage=100, with_inc=False, train_inc=False,
+                    thr_sv=None, use_loss_mask=False):
+        """One pass over every block (smoe.py:1606-1793).  Returns (loss, mse, num_pi, num_sv)."""
+        if with_quantized_params:
+            raise NotImplementedError("quantised-parameter passes are a 'next' row (SURVEY 8(f-3))")
+        if sampling_percentage != 100:
+            raise NotImplementedError("pixel sub-sampling is not part of the hot path")
+        if with_inc or train_inc:
+            raise NotImplementedError("kernel adding is out of scope")
+        self.valid = False
+        self._make_engine(pis_l1, u_l1)
+        eng = self._engine
+        if train:
+            assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
+            loss = torch.empty((self.B,), dtype=torch.float32, device=eng.device)
+            sse = torch.empty((self.B,), dtype=torch.float32, device=eng.device)
+            eng.fit(self._target, self._params, self._state, self._active, 1, loss_w=self._loss_w,
+                    diverged=self._diverged, loss0=self._loss0, loss_out=loss, sse_out=sse)
+        else:
+            out = eng.forward(self._target, self._params, self._active, loss_w=self._loss_w,
+                              want_recon=update_reconstruction, want_argmax=update_reconstruction,
+                              want_gate=update_reconstruction)
+            loss, sse = out["loss"], out["sse"]
+            if update_reconstruction:
+                self._stitch(out)
+        loss_val, mse_val, num_pi = self._global(loss, sse)
+        self._last_block_loss = loss
+        return loss_val, mse_val, num_pi, 0
+
+    def _stitch(self, out):
+        """Assemble the full-image reconstruction / argmax / gate arrays (smoe.py:1719-1783)."""
+        bs, d = self.batch_size_valued, self.dim_domain
+        recon = blk.from_planar(out["recon"].cpu().numpy(), bs)                       # (B,*bs,C)
+        recon = sdist.allgather_blocks(recon, self.num_blocks)
+        self.reconstruction_image = blk.blocks_to_image(recon, self.image.shape[:d], bs)
+        am = out["argmax"].cpu().numpy().astype(np.int64).reshape((self.B,) + bs)
+        am = am + (np.arange(self.lo, self.hi, dtype=np.int64) * self.kernels).reshape((-1,) + (1,) * d)
+        am = sdist.allgather_blocks(am, self.num_blocks)
+        self.weight_matrix_argmax = blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
+        gate = out["gate_w"].cpu().numpy().reshape((self.B, self.kernels) + bs)
+        self.weight_matrix = sdist.allgather_blocks(gate, self.num_blocks)            # (B,K,*bs)
+        self.valid = True
+
+    # -- training loop (smoe.py:1485-1603) -------------------------------------------------
+    def train(self, num_iter, val_iter=100, ukl_iter=None, optimizer1=None, optimizer2=None, optimizer3=None,
+              grad_clip_value_abs=None, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, sampling_percentage=100,
+              callbacks=(), with_inc=False, train_inc=False, train_orig=True, use_loss_mask=False):
+        if ukl_iter is None:
+            ukl_iter = val_iter
+        if optimizer1:
+            self.set_optimizer(optimizer1, optimizer2, optimizer3, grad_clip_value_abs=grad_clip_value_abs)
+        assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
+        if sampling_percentage != 100 or with_inc or train_inc or not train_orig:
+            raise NotImplementedError("sampling / kernel-adding options are outside the hot path")
+        self._make_engine(pis_l1, u_l1)
+        eng = self._engine
+
+        # iteration-0 evaluation (smoe.py:1507-1519)
+        self.best_loss, self.best_mse, num_pi, num_sv = self.run_batched(
+            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+        if self._loss0 is None:
+            self._loss0 = self._last_block_loss.clone()
+        if self._best_loss_blocks is None:
+            self._best_loss_blocks = self._last_block_loss.clone()
+            for k in PARAM_NAMES:
+                self._best[k].copy_(self._params[k])
+        self.losses.append((self.iter, self.best_loss))
+        self.mses.append((self.iter, self.best_mse))
+        self.num_pis.append((self.iter, num_pi))
+        self.num_svs.append((self.iter, num_sv))
+        for callback in callbacks:
+            callback(self)
+
+        loss_val, mse_val = self.best_loss, self.best_mse
+        i = 0
+        try:
+            while i < num_iter:
+                # run up to the next validation / kernel-list boundary in ONE launch
+                nxt = min(num_iter, (i // val_iter + 1) * val_iter, (i // ukl_iter + 1) * ukl_iter)
+                n = nxt - i
+                eng.fit(self._target, self._params, self._state, self._active, n, loss_w=self._loss_w,
+                        diverged=self._diverged, loss0=self._loss0)
+                i = nxt
+                self.iter += n
+                self.valid = False
+                validate = i % val_iter == 0
+                if i % ukl_iter == 0:                                         # smoe.py:1531-1536
+                    eng.update_kernel_list(self._params, self._active)
+                    if not validate:
+                        loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
+                if validate:                                                  # smoe.py:1538-1594
+                    loss_val, mse_val, num_pi, num_sv = self.run_batched(
+                        pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+                    # global divergence rule at validation cadence (per block it is applied on the
+                    # device every iteration, smoe.py:1565-1570)
+                    if np.isnan(loss_val) or (len(self.losses) > 0 and loss_val + 1 > (self.losses[0][1] + 100) * 10):
+                        print("stop")
+                        break
+                    eng.checkpoint_best(self._last_block_loss, self._best_loss_blocks, self._params, self._best)
+                    if not self.best_loss or loss_val < self.best_loss:
+                        self.best_loss = loss_val
+                    self.losses.append((self.iter, loss_val))
+                    if not self.best_mse or mse_val < self.best_mse:
+                        self.best_mse = mse_val
+                    self.mses.append((self.iter, mse_val))
+                    self.num_pis.append((self.iter, num_pi))
+                    self.num_svs.append((self.iter, num_sv))
+                    for callback in callbacks:
+                        callback(self)
+        except KeyboardInterrupt:
+            pass
+        self.losses_history.append(self.losses)
+        self.mses_history.append(self.mses)
+        if self.rank == 0:
+            print("end loss/mse: ", loss_val, "/", mse_val, "@iter: ", i)
+            print("best loss/mse: ", self.best_loss, "/", self.best_mse)
+
+    # -- getters (smoe.py:1795-1888) ------------------------------------------------------------
+    def _gather_params(self, p: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
+        return {k: sdist.allgather_blocks(v.cpu().numpy().copy(), self.num_blocks) for k, v in p.items()}
+
+    def get_params(self):
+        return self._gather_params(self._params)
+
+    def get_best_params(self):
+        return self._gather_params(self._best)
+
+    def get_reconstruction(self):
+        if not self.valid:
+            self.run_batched(train=False, update_reconstruction=True)
+        return self.reconstruction_image
+
+    def get_weight_matrix_argmax(self):
+        if not self.valid:
+            self.run_batched(train=False, update_reconstruction=True)
+        return self.weight_matrix_argmax
+
+    def get_weight_matrix(self):
+        if not self.valid:
+            self.run_batched(train=False, update_reconstruction=True)
+        return self.weight_matrix
+
+    def get_psnr(self) -> float:
+        """PSNR of the current reconstruction over the valid pixels (plotter.py:14-15)."""
+        rec = self.get_reconstruction()
+        mse = float(np.mean((rec.astype(np.float64) - self.image.astype(np.float64)) ** 2))
+        return float(-10.0 * np.log10(mse))
+
+    def get_losses(self):
+        return self.losses
+
+    def get_mses(self):
+        return self.mses
+
+    def get_num_pis(self):
+        return self.num_pis
+
+    def get_num_svs(self):
+        return self.num_svs
+
+    def get_best_loss(self):
+        return self.best_loss
+
+    def get_best_mse(self):
+        return self.best_mse
+
+    def get_losses_history(self):
+        return self.losses_history
+
+    def get_mses_history(self):
+        return self.mses_history
+
+    def get_iter(self):
+        return self.iter
+
+    def get_original_image(self):
+        return np.squeeze(self.image)
+
+    # -- checkpoint / restore (replaces the tf.train.Saver of smoe.py:1066-1077) ---------------
+    def checkpoint(self, path):
+        st = {"params": {k: v.cpu().numpy().copy() for k, v in self._params.items()},
+              "best": {k: v.cpu().numpy().copy() for k, v in self._best.items()},
+              "m": {k: v.cpu().numpy().copy() for k, v in self._state.m.items()},
+              "v": {k: v.cpu().numpy().copy() for k, v in self._state.v.items()},
+              "beta_pow": (float(self._state.c.beta1_power), float(self._state.c.beta2_power)),
+              "step": int(self._state.c.step), "active": self._active.cpu().numpy(),
+              "diverged": self._diverged.cpu().numpy(), "iter": self.iter, "losses": self.losses,
+              "mses": self.mses, "num_pis": self.num_pis, "shard": (self.lo, self.hi, self.num_blocks)}
+        with open(path if self.world_size == 1 else f"{path}.rank{self.rank}", "wb") as fd:
+            pickle.dump(st, fd)
+        return path
+
+    def restore(self, path):
+        with open(path if self.world_size == 1 else f"{path}.rank{self.rank}", "rb") as fd:
+            st = pickle.load(fd)
+        assert tuple(st["shard"]) == (self.lo, self.hi, self.num_blocks), "checkpoint belongs to another sharding"
+        dev = self._engine.device
+        for k in PARAM_NAMES:
+            self._params[k].copy_(torch.from_numpy(st["params"][k]).to(dev))
+            self._best[k].copy_(torch.from_numpy(st["best"][k]).to(dev))
+            self._state.m[k].copy_(torch.from_numpy(st["m"][k]).to(dev))
+            self._state.v[k].copy_(torch.from_numpy(st["v"][k]).to(dev))
+        self._state.c.beta1_power, self._state.c.beta2_power = st["beta_pow"]
+        self._state.c.step = st["step"]
+        self._active.copy_(torch.from_numpy(st["active"]).to(dev))
+        self._diverged.copy_(torch.from_numpy(st["diverged"]).to(dev))
+        self.iter = st["iter"]
+        self.losses, self.mses, self.num_pis = st["losses"], st["mses"], st["num_pis"]
+        self.valid = False

@@ -1,0 +1,49 @@
+"""Decode-side entry point (reference smoe_reconstruction.py:15-79): parameter pickle ->
+``Smoe(init_params=...)`` -> ONE forward pass -> reconstructed image.
+
+    python -m steered_mixture_of_experts_amd.smoe_reconstruction -i IMG -r OUT -p params.pkl
+"""
+import argparse
+import os
+import re
+
+from .smoe import Smoe
+from .utils import load_checkpoint, read_image, write_image
+
+
+def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6, 10, 10), quant_params=False):
+    if len(bit_depths) != 5:
+        raise ValueError("Number of bit depths must be five!")           # smoe_reconstruction.py:17-18
+    if quant_params:
+        raise NotImplementedError("reconstruction from quantised parameters is a 'next' row (SURVEY 8(f-3))")
+    orig, precision, _ = read_image(image_path)
+    cp = load_checkpoint(params_file)
+    init_params = cp['params']
+    if results_path is not None and not os.path.exists(results_path):
+        os.mkdir(results_path)
+    smoe = Smoe(orig, init_params=init_params, start_batches=batches, batch_size=list(cp['batch_size']),
+                bit_depths=list(bit_depths), precision=precision,
+                use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)))
+    loss, mse, _, _ = smoe.run_batched(train=False, update_reconstruction=True)
+    found = re.findall(r'\d+', os.path.basename(params_file))
+    iter_str = found[-1] if found else "0"
+    reconstruction_path = results_path + '/' + iter_str + "_reconstruction"
+    reconstruction = smoe.get_reconstruction()
+    write_image(reconstruction, reconstruction_path, smoe.dim_domain, smoe.use_yuv, precision)
+    return reconstruction, loss, mse
+
+
+def _cli():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-i', '--image_path', type=str, required=True, help="input image")
+    parser.add_argument('-r', '--results_path', type=str, required=True, help="results path")
+    parser.add_argument('-p', '--params_file', type=str, required=True, help="parameter file for model initialization.")
+    parser.add_argument('-b', '--batches', type=int, default=1)
+    parser.add_argument('-bd', '--bit_depths', type=int, default=[20, 18, 6, 10, 10], nargs='+')
+    parser.add_argument('-qp', '--quant_params', action='store_true')
+    args = parser.parse_args()
+    main(**vars(args))
+
+
+if __name__ == '__main__':
+    _cli()

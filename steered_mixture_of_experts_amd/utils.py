@@ -1,0 +1,89 @@
+"""Model / image IO in the reference's formats (reference utils.py:18-162).  The pickle
+schema written by ``save_model`` and read by ``load_params`` is the reference's
+(``{'params', 'mses', 'losses', 'num_pis', flags...}``, utils.py:30-59) with the per-block
+leading axis kept; image codecs (cv2, hdf5storage) are not rebuilt -- ``read_image`` handles
+.npy / .npz arrays and, when Pillow is importable, ordinary image files."""
+import pickle
+
+import numpy as np
+
+
+def psnr(mse, precision):
+    """plotter.py:14-15: mse is mse_op, i.e. mean(diff^2) * (2^p)^2 (smoe.py:1053)."""
+    return 10 * np.log10((2 ** precision) ** 2 / mse)
+
+
+def save_model(smoe, path, best=False, reduce=False, quantize=False):
+    """utils.py:18-59.  ``reduce`` (dropping pis<=0 kernels) would make the per-block arrays
+    ragged and is therefore off by default; ``quantize`` needs the parameter quantiser
+     and is refused."""
+    if quantize:
+        raise NotImplementedError("parameter quantisation is a 'next' row (SURVEY 8(f-3))")
+    params = smoe.get_best_params() if best else smoe.get_params()
+    if reduce:
+        raise NotImplementedError("reduce=True would drop the block structure of per-block parameters")
+    cp = {'params': params, 'mses': smoe.get_mses(), 'losses': smoe.get_losses(), 'num_pis': smoe.get_num_pis(),
+          'quantization_mode': smoe.quantization_mode, 'quantized_pis': smoe.quantize_pis,
+          'lower_bounds': smoe.lower_bounds, 'upper_bounds': smoe.upper_bounds,
+          'use_yuv': smoe.use_yuv, 'only_y_gamma': smoe.only_y_gamma, 'ssim_opt': smoe.ssim_opt,
+          'use_determinant': smoe.use_determinant, 'use_diff_center': smoe.use_diff_center,
+          # additions needed to rebuild the block tiling
+          'batch_size': tuple(smoe.batch_size_valued), 'shape_of_img': tuple(smoe.image.shape)}
+    if smoe.rank == 0:
+        with open(path, 'wb') as fd:
+            pickle.dump(cp, fd)
+    return cp
+
+
+def load_params(path):
+    """utils.py:61-65."""
+    with open(path, 'rb') as fd:
+        return pickle.load(fd)['params']
+
+
+def load_checkpoint(path):
+    with open(path, 'rb') as fd:
+        return pickle.load(fd)
+
+
+def read_image(path, use_yuv=True):
+    """utils.py:68-134 for array inputs: returns (float32 image in [0,1], precision, affines)."""
+    if path.lower().endswith('.npy'):
+        orig = np.load(path)
+    elif path.lower().endswith('.npz'):
+        orig = np.load(path)["imgs"]
+    else:
+        try:
+            from PIL import Image
+        except ImportError as e:                                     # pragma: no cover
+            raise ValueError("Unknown data format (Pillow is not available for image files)") from e
+        orig = np.asarray(Image.open(path))
+    if orig.ndim == 2:
+        orig = orig[..., None]
+    if orig.dtype == np.uint8:
+        orig = orig.astype(np.float32) / 255.                        # utils.py:126-128
+        precision = 8
+    elif orig.dtype == np.uint16:
+        orig = orig.astype(np.float32) / 2 ** 16.                    # utils.py:129-131
+        precision = 16
+    else:
+        orig = orig.astype(np.float32)
+        precision = 8
+    return orig, precision, None
+
+
+def write_image(img, path, type=2, yuv=False, precision=8):
+    """utils.py:136-162, array output: the rounded integer image as .npy (and .png when
+    Pillow is importable and the image is 2-D)."""
+    if precision == 8:
+        out = np.uint8(np.round(img * 255))
+    else:
+        out = np.uint16(np.round(img * 2 ** precision))
+    np.save(path + ".npy", out)
+    if type == 2:
+        try:
+            from PIL import Image
+            Image.fromarray(np.squeeze(out)).save(path + ".png")
+        except Exception:                                            # pragma: no cover
+            pass
+    return out

@@ -1,0 +1,119 @@
+"""Test double of ``BlockEngine`` built on the plain-C oracle (oracle/smoe_oracle.c), working on
+torch CPU tensors.  TEST INFRASTRUCTURE: lets the CPU suite drive the ``Smoe`` facade's host
+logic (iteration scheduling, validation cadence, best snapshot, sharding, scalar all-reduce)
+without a GPU.  Never imported by the product."""
+import numpy as np
+import torch
+
+from oracle import c_oracle as co
+from oracle import smoe_oracle as o
+
+NAMES = o.PARAM_NAMES
+
+
+class _State:
+    def __init__(self, params, b1, b2):
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.beta_pow = np.array([b1, b2], np.float32)
+        self._step = 0
+
+        class _C:
+            pass
+        self.c = _C()
+        self.c.beta1_power, self.c.beta2_power, self.c.step = b1, b2, 0
+
+    @property
+    def step(self):
+        return self._step
+
+
+class OracleEngine:
+    def __init__(self, cfg, device=None):
+        self.cfg = cfg
+        self.device = torch.device("cpu")
+        self.ocfg = o.OracleConfig(
+            block_shape=tuple(cfg.block_shape), channels=cfg.channels, kernels=cfg.kernels,
+            precision=cfg.precision, margin=cfg.margin, use_determinant=cfg.use_determinant, use_yuv=cfg.use_yuv,
+            train_pis=cfg.train_pis, train_gammas=cfg.train_gammas, train_musx=cfg.train_musx,
+            lr_expert=cfg.lr_expert, lr_pis=cfg.lr_pis, lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2,
+            adam_eps=cfg.adam_eps, grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1,
+            start_pis=cfg.start_pis or cfg.kernels)
+        self.coords = np.ascontiguousarray(o.block_coords(cfg.block_shape).T)
+
+    def close(self):
+        pass
+
+    def new_adam_state(self, params):
+        return _State(params, self.cfg.beta1, self.cfg.beta2)
+
+    @staticmethod
+    def _np(d):
+        return {k: d[k].numpy() for k in NAMES}
+
+    def forward(self, target, params, active, loss_w=None, want_recon=True, want_argmax=False, want_gate=False,
+                update_active=True):
+        B = target.shape[0]
+        act = active.numpy().view(np.uint32)
+        p = self._np(params)
+        if want_argmax or want_gate:
+            # the C oracle has no argmax / gate outputs: use the numpy one for those
+            K = self.cfg.kernels
+            mask = ((act[:, None] >> np.arange(K, dtype=np.uint32)[None, :]) & 1).astype(bool)
+            tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
+            f = o.forward(p, tgt, self.coords.T, mask, self.ocfg, None if loss_w is None else loss_w.numpy(), np.float32)
+            out = {"loss": torch.from_numpy(f["loss"].astype(np.float32)), "sse": torch.from_numpy(f["sse"].astype(np.float32)),
+                   "recon": torch.from_numpy(np.ascontiguousarray(f["recon"].transpose(0, 2, 1))),
+                   "argmax": torch.from_numpy(f["argmax"].astype(np.uint8)),
+                   "gate_w": torch.from_numpy(np.ascontiguousarray(f["wt"]))}
+            if update_active:
+                bits = (f["active_new"].astype(np.uint32) << np.arange(K, dtype=np.uint32)[None, :]).sum(axis=1)
+                act[:] = bits.astype(np.uint32)
+            return out
+        r = co.forward(self.ocfg, self.coords, target.numpy(), p, act, None if loss_w is None else loss_w.numpy(),
+                       want_recon=want_recon, update_active=update_active)
+        return {"loss": torch.from_numpy(r["loss"]), "sse": torch.from_numpy(r["sse"]),
+                "recon": None if r["recon"] is None else torch.from_numpy(r["recon"]), "argmax": None, "gate_w": None}
+
+    def fit(self, target, params, state, active, n_iters, loss_w=None, diverged=None, loss0=None, loss_out=None,
+            sse_out=None):
+        act = active.numpy().view(np.uint32)
+        state.beta_pow[:] = [state.c.beta1_power, state.c.beta2_power]      # restore() writes the c fields
+        r = co.fit(self.ocfg, self.coords, target.numpy(), self._np(params), self._np(state.m), self._np(state.v), act,
+                   n_iters, state.beta_pow, None if loss_w is None else loss_w.numpy(),
+                   None if diverged is None else diverged.numpy().view(np.uint32),
+                   None if loss0 is None else loss0.numpy())
+        state._step = int(state.c.step) + n_iters
+        state.c.beta1_power, state.c.beta2_power, state.c.step = float(state.beta_pow[0]), float(state.beta_pow[1]), state._step
+        if loss_out is not None:
+            loss_out.copy_(torch.from_numpy(r["loss"]))
+        if sse_out is not None:
+            sse_out.copy_(torch.from_numpy(r["sse"]))
+
+    def update_kernel_list(self, params, active):
+        K = self.cfg.kernels
+        act = active.numpy().view(np.uint32)
+        mask = ((act[:, None] >> np.arange(K, dtype=np.uint32)[None, :]) & 1).astype(bool)
+        new = o.readmit(self._np(params), mask, self.ocfg, np.float32)
+        act[:] = (new.astype(np.uint32) << np.arange(K, dtype=np.uint32)[None, :]).sum(axis=1).astype(np.uint32)
+
+    def checkpoint_best(self, loss, best_loss, params, best):
+        better = loss < best_loss
+        for k in NAMES:
+            bm = better.reshape((-1,) + (1,) * (params[k].dim() - 1))
+            best[k].copy_(torch.where(bm, params[k], best[k]))
+        best_loss.copy_(torch.where(better, loss, best_loss))
+
+    def reduce_scalars(self, loss, sse, active):
+        N = self.cfg.pixels
+        out = torch.zeros(3, dtype=torch.float64)
+        if loss is not None:
+            out[0] = loss.double().sum() * N
+        if sse is not None:
+            out[1] = sse.double().sum()
+        if active is not None:
+            out[2] = float(sum(bin(int(x) & 0xFFFFFFFF).count("1") for x in active.numpy().view(np.uint32)))
+        return out
+
+    def fit_variant(self, B):
+        return "oracle"

@@ -1,0 +1,122 @@
+"""CPU tests of the ``Smoe`` facade's host logic, driven through a test double of the engine
+(tests/fake_engine.py, plain-C oracle): entry-point names and layouts of the reference,
+iteration / validation / kernel-list cadence (smoe.py:1485-1603), best snapshot, histories,
+padding, checkpoint round trip, and the loud refusal of options outside the hot path."""
+import numpy as np
+import pytest
+
+from fake_engine import OracleEngine
+from oracle import smoe_oracle as o
+from steered_mixture_of_experts_amd import blocks as blk
+from steered_mixture_of_experts_amd.smoe import Adam, Smoe
+from steered_mixture_of_experts_amd import utils
+
+
+def _image(h, w, C=1, seed=0):
+    gh, gw = -(-h // 16), -(-w // 16)
+    b = blk.synthetic_blocks(gh * gw, (16, 16), C, seed)
+    return blk.blocks_to_image(b, (gh * 16, gw * 16), (16, 16))[:h, :w]
+
+
+def _make(img, **kw):
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    return s
+
+
+def test_train_matches_the_numpy_restatement():
+    img = _image(64, 48)
+    s = _make(img)
+    assert s.num_blocks == 12 and s.start_batches == 12 and s.kernels == 4 and s.dim_domain == 2
+    s.train(20, val_iter=10)
+    blocks, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4)
+    tgt = blocks.reshape(12, -1, 1)
+    p0 = o.init_params(blocks, [2, 2])
+    pn, st, info = o.fit(p0, tgt, o.block_coords((16, 16)), cfg, 20, val_iter=10, dtype=np.float32)
+    got = s.get_params()
+    assert set(got) == {"pis", "musX", "A_diagonal", "A_corr", "gamma_e", "nu_e"}
+    assert got["A_diagonal"].shape == (12, 4, 2, 2) and got["gamma_e"].shape == (12, 4, 2, 1)
+    for k in ("nu_e", "musX", "pis", "gamma_e"):
+        assert np.abs(got[k] - pn[k]).max() < 5e-4, k
+    assert [it for it, _ in s.get_losses()] == [0, 10, 20] and s.get_iter() == 20
+    want_loss = [float(np.mean(l)) for l in info["hist"]["loss"]]
+    assert np.allclose([v for _, v in s.get_losses()], want_loss, rtol=2e-2)
+    want_mse = [float(np.sum(e) / (12 * 256) * 65536) for e in info["hist"]["sse"]]
+    assert np.allclose([v for _, v in s.get_mses()], want_mse, rtol=2e-2)
+    assert s.get_num_pis()[-1][1] == 48
+    # first evaluation is exact (same initial parameters, same maths)
+    assert abs(s.get_losses()[0][1] - want_loss[0]) < 1e-7
+    rec = s.get_reconstruction()
+    assert rec.shape == img.shape and rec.dtype == np.float32
+    am = s.get_weight_matrix_argmax()
+    assert am.shape == (64, 48) and am.max() < 48 and (am[:16, :16] < 4).all() and (am[16:32, :16] // 4 == 3).all()
+    assert s.get_weight_matrix().shape == (12, 4, 16, 16)
+    best = s.get_best_params()
+    assert np.abs(best["nu_e"] - info["best"]["nu_e"]).max() < 5e-4
+    assert abs(s.get_psnr() - (-10 * np.log10(np.mean((rec.astype(np.float64) - img) ** 2)))) < 1e-9
+
+
+def test_single_block_is_configs0():
+    img = blk.synthetic_blocks(1, (16, 16), 1, 7)[0]
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[None], use_determinant=True, engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    assert s.num_blocks == 1 and s.batch_size_valued == (16, 16)
+    loss, mse, num_pi, num_sv = s.run_batched(train=False, update_reconstruction=True)
+    assert num_pi == 4 and num_sv == 0
+    l2, _, _, _ = s.run_batched(train=True)
+    assert abs(l2 - loss) < 1e-7        # a train pass reports the loss at the parameters it started from
+    assert len(s.kernel_list_per_batch) == 1 and s.kernel_list_per_batch[0].dtype == bool
+
+
+def test_padded_image_and_loss_mask():
+    img = _image(40, 37, C=3, seed=3)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True,
+             engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    assert s.padded and s.num_blocks == 9 and s.use_yuv
+    s.train(4, val_iter=2)
+    assert s.get_reconstruction().shape == (40, 37, 3)
+    g = Smoe(img[..., :1], kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
+    assert not g.use_yuv                      # forced off unless C == 3 (smoe_test.py:41-44)
+
+
+def test_checkpoint_restore_and_model_pickle(tmp_path):
+    img = _image(32, 32)
+    s = _make(img)
+    s.train(6, val_iter=3)
+    path = str(tmp_path / "ckpt.pkl")
+    s.checkpoint(path)
+    ref = s.get_params()
+    s.train(3, val_iter=3)
+    after = s.get_params()
+    t = _make(img)
+    t.restore(path)
+    assert all(np.array_equal(t.get_params()[k], ref[k]) for k in ref) and t.get_iter() == 6
+    t.train(3, val_iter=3)
+    again = t.get_params()
+    assert all(np.array_equal(again[k], after[k]) for k in ref)      # resume is exact (Adam slots + beta powers)
+    mp = str(tmp_path / "params_10.pkl")
+    utils.save_model(s, mp)
+    cp = utils.load_checkpoint(mp)
+    assert set(cp) >= {"params", "mses", "losses", "num_pis", "use_yuv", "use_determinant", "batch_size"}
+    assert np.array_equal(utils.load_params(mp)["nu_e"], after["nu_e"])
+    r = Smoe(img, init_params=cp["params"], batch_size=list(cp["batch_size"]), use_determinant=True,
+             engine_factory=OracleEngine)
+    assert np.array_equal(r.get_reconstruction(), s.get_reconstruction())
+
+
+def test_options_outside_the_hot_path_are_refused():
+    img = _image(16, 16)
+    for kw in ({"ssim_opt": True}, {"quantization_mode": 2}, {"overlap_of_batches": 2}, {"add_kernel_slots": 4},
+               {"train_svs": True}, {"radial_as": True}, {"train_inverse_cov": True}, {"use_diff_center": True}):
+        with pytest.raises(NotImplementedError):
+            Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
+    with pytest.raises(AssertionError):
+        Smoe(img, batch_size=[16, 16], engine_factory=OracleEngine)
+    with pytest.raises(ValueError):
+        Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16, 4], engine_factory=OracleEngine)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
+    with pytest.raises(AssertionError):
+        s.train(1)                               # "no optimizer found" (smoe.py:1492)
+    assert utils.psnr(65536.0 * 1e-3, 8) == pytest.approx(30.0)

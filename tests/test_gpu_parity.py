@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import smoe_oracle as o
+from steered_mixture_of_experts_amd.blocks import synthetic_blocks
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +50,7 @@ def _bits_to_mask(bits, K):
 
 def _setup(shape, C, kpd, yuv, B, seed, perturb=True, **cfgkw):
     K = int(np.prod(kpd))
-    blk = o.synthetic_blocks(B, shape, C, seed)
+    blk = synthetic_blocks(B, shape, C, seed)
     p = o.init_params(blk, kpd)
     rng = np.random.default_rng(seed + 1)
     if perturb:
