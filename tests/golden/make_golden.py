@@ -37,8 +37,13 @@ for idx, (name, shape, C, kpd, yuv) in enumerate(CASES):
     coords = o.block_coords(shape, np.float64)
     tgt = blk.reshape(B, -1, C)
     act = np.ones((B, K), bool)
-    f = o.forward(p, tgt, coords, act, cfg, None, np.float64, want_grads=True)
-    pn, _, info = o.fit(p, tgt, coords, cfg, N_ITERS, val_iter=10 ** 9, dtype=np.float64)
+    # TF computes in fp32: the lattice values (and with them sign(q - t) at exactly reconstructed
+    # pixels) are those of the fp32 restatement; loss / gradients are then evaluated in fp64 GIVEN
+    # these lattice values, and the short fit is the fp32 restatement's.
+    f32 = o.forward(p, tgt, o.block_coords(shape), act, cfg, None, np.float32)
+    f = o.forward(p, tgt, coords, act, cfg, None, np.float64, want_grads=True, q_override=f32["recon"])
+    f["recon"] = f32["recon"]
+    pn, _, info = o.fit(p, tgt, o.block_coords(shape), cfg, N_ITERS, val_iter=10 ** 9, dtype=np.float32)
     out = {"block_shape": np.array(shape), "channels": C, "kernels": K, "use_yuv": yuv, "n_iters": N_ITERS,
            "target": tgt.astype(np.float32), "loss": f["loss"], "sse": f["sse"],
            "recon": f["recon"].astype(np.float32), "y": f["y"], "active_after_fit": info["active"]}
