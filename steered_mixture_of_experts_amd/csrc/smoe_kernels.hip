@@ -29,6 +29,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// A value that is the same in every lane of the wavefront -> scalar register.
+__device__ __forceinline__ float to_sgpr(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -162,6 +166,25 @@ struct BlockRegs {
         }
     }
 };
+
+// G == 64: the wavefront owns ONE block, so everything derived from its parameters is
+// wave-uniform and could live in SGPRs.  Measured on MI355X this is a LOSS (VALU forms with an
+// SGPR source issue at ~4.8 vs ~3.2 cycles and the readfirstlanes add ~100 instructions per
+// iteration: 32x32/K=8/C=3 went 63 -> 49 Gpx-it/s), so it is not called; kept for reference.
+template <int D, int C, int K>
+__device__ __forceinline__ void uniformize(BlockRegs<D, C, K>& R) {
+    using Lt = Layout<D, C, K>;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        R.coef[k] = to_sgpr(R.coef[k]);
+#pragma unroll
+        for (int i = 0; i < Lt::TRI; ++i) R.As[k][i] = to_sgpr(R.As[k][i]);
+#pragma unroll
+        for (int m = 0; m < D; ++m) R.cz[k][m] = to_sgpr(R.cz[k][m]);
+#pragma unroll
+        for (int i = Lt::O_NU; i < Lt::PK; ++i) R.P[k * Lt::PK + i] = to_sgpr(R.P[k * Lt::PK + i]);
+    }
+}
 
 template <int D, int C, int K>
 __device__ __forceinline__ void hoist_last(BlockRegs<D, C, K>& R, float xl) {
