@@ -63,8 +63,9 @@ class Smoe:
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"Smoe({name}=True) is outside the per-block hot path (SURVEY section 8)")
-        if quantization_mode != 0 or quantize_pis:
-            raise NotImplementedError("quantisation-aware fitting is a 'next' row (SURVEY 8(f-3))")
+        if quantization_mode not in (0, 1):
+            raise NotImplementedError("quantisation-aware fitting (fake-quant modes 2/3) is outside the hot path; "
+                                      "mode 1 (quantise at validation, quantizer.py) is supported")
         if add_kernel_slots:
             raise NotImplementedError("progressive kernel adding changes K over time; not part of the hot path")
         if overlap_of_batches:
@@ -189,6 +190,12 @@ class Smoe:
         self.reconstruction_image = None
         self.weight_matrix_argmax = None
         self.weight_matrix = None
+        self.qvalid = False
+        self.qreconstruction_image = None
+        self.qweight_matrix_argmax = None
+        self.qweight_matrix = None
+        self.best_qloss = None
+        self.best_qmse = []
 
     # ------------------------------------------------------------------------------------
     def _make_engine(self, pis_l1: float, u_l1: float):
@@ -246,8 +253,6 @@ class Smoe:
                     with_quantized_params=False, sampling_percentage=100, with_inc=False, train_inc=False,
                     thr_sv=None, use_loss_mask=False):
         """One pass over every block (smoe.py:1606-1793).  Returns (loss, mse, num_pi, num_sv)."""
-        if with_quantized_params:
-            raise NotImplementedError("quantised-parameter passes are a 'next' row (SURVEY 8(f-3))")
         if sampling_percentage != 100:
             raise NotImplementedError("pixel sub-sampling is not part of the hot path")
         if with_inc or train_inc:
@@ -255,6 +260,26 @@ class Smoe:
         self.valid = False
         self._make_engine(pis_l1, u_l1)
         eng = self._engine
+        if with_quantized_params:
+            # smoe.py:1688-1689: the rescaled parameters are fed over the masked-parameter tensors;
+            # the kernel lists are not touched (smoe.py:1763)
+            assert self.rparams is not None, "quantize_params + rescaler first (smoe.py:1499-1501)"
+            self.qvalid = False
+            dev = eng.device
+            rp = {k: torch.from_numpy(np.ascontiguousarray(self.rparams[k][self.lo:self.hi], dtype=np.float32)).to(dev)
+                  for k in PARAM_NAMES}
+            out = eng.forward(self._target, rp, self._active, loss_w=self._loss_w,
+                              want_recon=update_reconstruction, want_argmax=update_reconstruction,
+                              want_gate=update_reconstruction, update_active=False)
+            if update_reconstruction:
+                keep = (self.reconstruction_image, self.weight_matrix_argmax, self.weight_matrix, self.valid)
+                self._stitch(out)
+                self.qreconstruction_image, self.qweight_matrix_argmax, self.qweight_matrix = \
+                    self.reconstruction_image, self.weight_matrix_argmax, self.weight_matrix
+                self.reconstruction_image, self.weight_matrix_argmax, self.weight_matrix, self.valid = keep
+                self.qvalid = True
+            loss_val, mse_val, num_pi = self._global(out["loss"], out["sse"])
+            return loss_val, mse_val, num_pi, 0
         if train:
             assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
             loss = torch.empty((self.B,), dtype=torch.float32, device=eng.device)
@@ -300,6 +325,14 @@ class Smoe:
         self._make_engine(pis_l1, u_l1)
         eng = self._engine
 
+        if self.quantization_mode >= 1:                                   # smoe.py:1498-1505
+            from .quantizer import quantize_params, rescaler
+            self.qparams = quantize_params(self, self.get_params())
+            self.rparams = rescaler(self, self.qparams)
+            self.best_qloss, self.best_qmse, _, _ = self.run_batched(
+                pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True, with_quantized_params=True)
+            self.qlosses.append((0, self.best_qloss))
+            self.qmses.append((0, self.best_qmse))
         # iteration-0 evaluation (smoe.py:1507-1519)
         self.best_loss, self.best_mse, num_pi, num_sv = self.run_batched(
             pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
@@ -334,6 +367,15 @@ class Smoe:
                     if not validate:
                         loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
                 if validate:                                                  # smoe.py:1538-1594
+                    if self.quantization_mode >= 1:                           # smoe.py:1539-1545
+                        from .quantizer import quantize_params, rescaler
+                        self.qparams = quantize_params(self, self.get_params())
+                        self.rparams = rescaler(self, self.qparams)
+                        qloss_val, qmse_val, _, _ = self.run_batched(
+                            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True,
+                            with_quantized_params=True)
+                        self.qlosses.append((i, qloss_val))                   # smoe.py:1585-1587
+                        self.qmses.append((i, qmse_val))
                     loss_val, mse_val, num_pi, num_sv = self.run_batched(
                         pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
                     # global divergence rule at validation cadence (per block it is applied on the
@@ -374,6 +416,17 @@ class Smoe:
         if not self.valid:
             self.run_batched(train=False, update_reconstruction=True)
         return self.reconstruction_image
+
+    def get_qreconstruction(self):
+        if not self.qvalid:
+            self.run_batched(train=False, update_reconstruction=True, with_quantized_params=True)
+        return self.qreconstruction_image
+
+    def get_qlosses(self):
+        return self.qlosses
+
+    def get_qmses(self):
+        return self.qmses
 
     def get_weight_matrix_argmax(self):
         if not self.valid:

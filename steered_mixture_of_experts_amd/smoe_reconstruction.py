@@ -14,8 +14,6 @@ from .utils import load_checkpoint, read_image, write_image
 def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6, 10, 10), quant_params=False):
     if len(bit_depths) != 5:
         raise ValueError("Number of bit depths must be five!")           # smoe_reconstruction.py:17-18
-    if quant_params:
-        raise NotImplementedError("reconstruction from quantised parameters is a 'next' row (SURVEY 8(f-3))")
     orig, precision, _ = read_image(image_path)
     cp = load_checkpoint(params_file)
     init_params = cp['params']
@@ -24,11 +22,23 @@ def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6
     smoe = Smoe(orig, init_params=init_params, start_batches=batches, batch_size=list(cp['batch_size']),
                 bit_depths=list(bit_depths), precision=precision,
                 use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)))
-    loss, mse, _, _ = smoe.run_batched(train=False, update_reconstruction=True)
+    smoe.quantization_mode = cp.get('quantization_mode') or 0          # smoe_reconstruction.py:32-43
+    smoe.quantize_pis = bool(cp.get('quantized_pis'))
+    smoe.lower_bounds, smoe.upper_bounds = cp.get('lower_bounds'), cp.get('upper_bounds')
+    with_q = bool(quant_params) and smoe.quantization_mode <= 0         # smoe_reconstruction.py:46-51
+    if with_q:
+        from .quantizer import quantize_params, rescaler
+        smoe.qparams = quantize_params(smoe, smoe.get_params())
+        smoe.rparams = rescaler(smoe, smoe.qparams)
+    loss, mse, _, _ = smoe.run_batched(train=False, update_reconstruction=True, with_quantized_params=with_q)
     found = re.findall(r'\d+', os.path.basename(params_file))
     iter_str = found[-1] if found else "0"
     reconstruction_path = results_path + '/' + iter_str + "_reconstruction"
-    reconstruction = smoe.get_reconstruction()
+    if with_q:                                                          # smoe_reconstruction.py:58-75
+        reconstruction = smoe.get_qreconstruction()
+        reconstruction_path += "_{0:1d}_{1:1d}_{2:1d}_{3:1d}_{4:1d}".format(*bit_depths)
+    else:
+        reconstruction = smoe.get_reconstruction()
     write_image(reconstruction, reconstruction_path, smoe.dim_domain, smoe.use_yuv, precision)
     return reconstruction, loss, mse
 

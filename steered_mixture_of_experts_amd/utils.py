@@ -15,10 +15,8 @@ def psnr(mse, precision):
 
 def save_model(smoe, path, best=False, reduce=False, quantize=False):
     """utils.py:18-59.  ``reduce`` (dropping pis<=0 kernels) would make the per-block arrays
-    ragged and is therefore off by default; ``quantize`` needs the parameter quantiser
-     and is refused."""
-    if quantize:
-        raise NotImplementedError("parameter quantisation is a 'next' row (SURVEY 8(f-3))")
+    ragged and is therefore off by default (the quantiser keeps a ``used_kernels`` mask
+    instead); ``quantize`` stores ``smoe.qparams`` with the reference's metadata keys."""
     params = smoe.get_best_params() if best else smoe.get_params()
     if reduce:
         raise NotImplementedError("reduce=True would drop the block structure of per-block parameters")
@@ -29,6 +27,16 @@ def save_model(smoe, path, best=False, reduce=False, quantize=False):
           'use_determinant': smoe.use_determinant, 'use_diff_center': smoe.use_diff_center,
           # additions needed to rebuild the block tiling
           'batch_size': tuple(smoe.batch_size_valued), 'shape_of_img': tuple(smoe.image.shape)}
+    if quantize:                                                     # utils.py:37-56
+        qparams = dict(smoe.qparams)
+        qparams.update({'dim_of_domain': smoe.dim_domain, 'dim_of_output': smoe.image.shape[-1],
+                        'shape_of_img': smoe.image.shape[:-1], 'used_ranges': False,
+                        'quantized_tria_params': True, 'trained_gamma': smoe.train_gammas,
+                        'trained_musx': smoe.train_musx, 'radial_as': smoe.radial_as,
+                        'trained_pis': smoe.train_pis, 'use_yuv': smoe.use_yuv,
+                        'only_y_gamma': smoe.only_y_gamma, 'use_determinant': smoe.use_determinant,
+                        'use_diff_center': smoe.use_diff_center})
+        cp.update({'qparams': qparams})
     if smoe.rank == 0:
         with open(path, 'wb') as fd:
             pickle.dump(cp, fd)

@@ -120,3 +120,59 @@ def test_options_outside_the_hot_path_are_refused():
     with pytest.raises(AssertionError):
         s.train(1)                               # "no optimizer found" (smoe.py:1492)
     assert utils.psnr(65536.0 * 1e-3, 8) == pytest.approx(30.0)
+
+
+def test_quantizer_matches_per_block_transcription_and_mode1_training():
+    from quantizer_ref import quantize_block
+    from steered_mixture_of_experts_amd.quantizer import quantize_params, rescaler
+    img = _image(48, 32)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=1,
+             bit_depths=[20, 18, 6, 10, 10], engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    s.train(6, val_iter=3)
+    assert [i for i, _ in s.get_qlosses()] == [0, 3, 6] and len(s.get_qmses()) == 3
+    p = s.get_params()
+    p["pis"][2, 1] = 0.0                      # a dropped kernel
+    q = quantize_params(s, p)
+    r = rescaler(s, q)
+    for b in range(s.num_blocks):
+        idx, qb, rb = quantize_block({k: v[b] for k, v in p.items()}, s.bit_depths)
+        assert np.array_equal(q["used_kernels"][b], idx)
+        for k in ("A_diagonal", "A_corr", "musX", "nu_e", "pis", "gamma_e"):
+            assert np.array_equal(q[k][b][idx], qb[k]), k
+            assert np.allclose(r[k][b][idx], rb[k], rtol=0, atol=1e-15), k
+        assert np.allclose(r["A"][b][idx], rb["A"])
+        assert (r["pis"][b][~idx] == 0).all()
+    # 6-bit nu_e: the rescaled expert means sit on a 63-step lattice between the block's min and max
+    lo, hi = q["lower_bounds"]["nu_e"], q["upper_bounds"]["nu_e"]
+    t = (r["nu_e"] - lo) / np.maximum(hi - lo, 1e-30) * 63
+    assert np.allclose(t, np.round(t), atol=1e-6)
+    # quantised reconstruction exists, differs little from the unquantised one
+    qr, rr = s.get_qreconstruction(), s.get_reconstruction()
+    assert qr.shape == rr.shape and np.abs(qr - rr).mean() < 0.02
+    # fixed bounds (quantize_pis) path
+    s.quantize_pis, s.lower_bounds, s.upper_bounds = True, [-2500, -.3, -5, 0, -32], [2500, 1.3, 5, 2, 32]
+    q2 = quantize_params(s, p)
+    assert q2["lower_bounds"]["pis"].max() == 0 and q2["upper_bounds"]["pis"].min() == 2
+
+
+def test_smoe_reconstruction_entry_point(tmp_path):
+    import steered_mixture_of_experts_amd.smoe_reconstruction as rec
+    import steered_mixture_of_experts_amd.smoe as smod
+    img = _image(32, 48)
+    s = _make(img)
+    s.train(4, val_iter=2)
+    np.save(tmp_path / "img.npy", np.uint8(np.round(img * 255)))
+    mp = str(tmp_path / "params_4.pkl")
+    utils.save_model(s, mp)
+    orig_factory = smod._default_engine_factory
+    smod._default_engine_factory = lambda cfg, device: OracleEngine(cfg, device)
+    try:
+        out = str(tmp_path / "out")
+        recon, loss, mse = rec.main(str(tmp_path / "img.npy"), out, mp)
+        assert np.array_equal(recon, s.get_reconstruction())
+        assert np.array_equal(np.load(out + "/4_reconstruction.npy"), np.uint8(np.round(recon * 255)))
+        recon_q, _, _ = rec.main(str(tmp_path / "img.npy"), out, mp, quant_params=True)
+        assert recon_q.shape == recon.shape and np.abs(recon_q - recon).mean() < 0.02
+    finally:
+        smod._default_engine_factory = orig_factory
