@@ -159,6 +159,62 @@ int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks);
 /* Force the lanes-per-block tiling (16, 64; 0 = automatic).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
 
+/* ---------------------------------------------------------------------------------------------
+ * Shared-kernel image mode: the reference's whole-image fit.  ONE global set of K
+ * kernels over the [0,1]^d image domain; the image is cut into batches (sliding_window,
+ * smoe.py:18-35); every batch evaluates the kernels of its kernel list (smoe.py:738-753); the
+ * gradients of all batches of a pass are accumulated (smoe.py:1148-1150) and one ApplyAdam step
+ * follows (smoe.py:1788).  overlap_of_batches = 0 only.
+ *   target [NB,C,Nb] (batch-planar, as the block layout)   params: get_params() layout, leading K
+ *   lists  [NB, KW] uint32 bitmaps, KW = smoe_shared_list_words(h) = ceil(K/32)
+ * For multi-GPU the host layer shards the BATCHES: every call takes the range
+ * [first_batch, first_batch + num_batches) and launch-local buffers; between
+ * smoe_shared_accumulate and smoe_shared_apply it all-reduces the buffer returned by
+ * smoe_shared_grad_buffer (K*P+K doubles) over the ranks (RCCL sum). */
+typedef struct smoe_shared_config {
+    int32_t abi_version, device, dim;
+    int32_t image_shape[SMOE_MAX_DIM];  /* pixels per axis (y, x[, t]), a multiple of batch_shape (smoe.py:239-241) */
+    int32_t batch_shape[SMOE_MAX_DIM];
+    int32_t channels, kernels, precision;
+    float   margin;
+    int32_t use_determinant, use_yuv, train_pis, train_gammas, train_musx;
+    float   lr_expert, lr_pis, lr_steer, beta1, beta2, adam_eps, grad_clip, pis_l1, u_l1;
+    int32_t start_pis;
+} smoe_shared_config;
+
+typedef struct smoe_shared_context* smoe_shared_handle;
+
+int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg);
+int smoe_shared_destroy(smoe_shared_handle h);
+int smoe_shared_num_batches(smoe_shared_handle h);
+int smoe_shared_list_words(smoe_shared_handle h);
+
+/* run_batched(train=False, update_reconstruction=True) (smoe.py:1606-1793).  recon [nb,C,Nb],
+ * argmax [nb,Nb] int32 (global kernel ids), loss/sse [nb]; any output may be NULL. */
+int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
+                        const smoe_params* p, float* recon, int32_t* argmax, float* loss, float* sse,
+                        uint32_t* lists, int32_t update_lists, void* stream);
+
+/* run_batched(train=True) minus train_op: forward + tf.gradients of the batches, accumulated into
+ * the handle's gradient buffer (accum_ops, smoe.py:1150); kernel lists pruned (smoe.py:1763-1766). */
+int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
+                           const smoe_params* p, float* loss, float* sse, uint32_t* lists, void* stream);
+
+/* train_op (smoe.py:1788): one ApplyAdam step per optimizer group on the accumulated gradients; clears
+ * the accumulators (zero_op, smoe.py:1613). */
+int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream);
+
+/* Device pointer + length (in doubles) of the gradient accumulation buffer. */
+int smoe_shared_grad_buffer(smoe_shared_handle h, double** dev_ptr, int64_t* count);
+
+/* n_iters x (accumulate over ALL batches; apply): the single-GPU loop body of Smoe.train. */
+int smoe_shared_fit(smoe_shared_handle h, const float* target, smoe_params* p, smoe_adam_state* s, int32_t n_iters,
+                    float* loss_last, float* sse_last, uint32_t* lists, void* stream);
+
+/* update_kernel_list (smoe.py:2287-2365) for the batches of the range. */
+int smoe_shared_update_kernel_list(smoe_shared_handle h, int32_t first_batch, int32_t num_batches,
+                                   const smoe_params* p, uint32_t* lists, void* stream);
+
 const char* smoe_last_error(void);
 int smoe_abi_version(void);
 

@@ -195,7 +195,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
             dtype=np.float32, want_grads: bool = False, q_override: Optional[np.ndarray] = None):
     """One pass of the reference graph over B independent blocks.
 
-    p: parameter dict with leading B.  target: (B, N, C).  coords: (N, d).
+    p: parameter dict with leading B.  target: (B, N, C).  coords: (N, d), or (B, N, d) when
+    every block/batch has its own pixel coordinates (shared-kernel mode: global domain).
     active: (B, K) bool = kernel_list (smoe.py:552).  loss_w: (B, N) or None.
     Returns a dict: y (pre-clip), w (gate), wt (masked gate), recon (quantised),
     loss (B,), sse (B,), mse_op (B,), active_new (B,K), argmax (B,N), num_pi (B,),
@@ -208,8 +209,10 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     T = dtype
     B, N, C = target.shape
     K = p["pis"].shape[1]
-    d = coords.shape[1]
-    x = coords.astype(T)                                    # (N,d)
+    d = coords.shape[-1]
+    x = coords.astype(T)
+    if x.ndim == 2:
+        x = np.broadcast_to(x[None], (B,) + x.shape)        # (B,N,d)
     t = target.astype(T)
     pis = p["pis"].astype(T)
     mu = p["musX"].astype(T)
@@ -222,7 +225,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     act = np.logical_and(active, pis > 0)                    # (B,K)
 
     # smoe.py:777-782,796: r = x - mu ; z = A^T r ; maha = |z|^2
-    r = x[None, None, :, :] - mu[:, :, None, :]              # (B,K,N,d)
+    r = x[:, None, :, :] - mu[:, :, None, :]                 # (B,K,N,d)
     z = np.einsum("bknl,bklm->bknm", r, A)                   # z_m = sum_l r_l A[l,m]
     maha = np.sum(z * z, axis=-1)                            # (B,K,N)
     n_exp = np.exp(T(-0.5) * maha)                           # smoe.py:807
@@ -250,7 +253,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     argmax = np.where(np.any(active_new, axis=1)[:, None], argmax, 0)
 
     # smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
-    e = nu[:, :, None, :] + np.einsum("bklc,nl->bknc", gam, x)   # (B,K,N,C)
+    e = nu[:, :, None, :] + np.einsum("bklc,bnl->bknc", gam, x)  # (B,K,N,C)
     if not cfg.train_gammas:
         e = np.broadcast_to(nu[:, :, None, :], (B, K, N, C)).astype(T)
     y = np.sum(wt[..., None] * e, axis=1)                    # (B,N,C)
@@ -286,7 +289,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     G = (cw[None, None, :] * T(2) * a * np.sign(diff) * lw[:, :, None]) * inside   # (B,N,C)
     # experts
     g_nu = np.einsum("bkn,bnc->bkc", wt, G)
-    g_gam = np.einsum("bkn,nl,bnc->bklc", wt, x, G)
+    g_gam = np.einsum("bkn,bnl,bnc->bklc", wt, x, G)
     # gate
     h = np.where(M, np.einsum("bknc,bnc->bkn", e, G), T(0))  # (B,K,N)
     dotp = np.sum(h * w, axis=1)                             # (B,N)
@@ -442,3 +445,102 @@ def fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int = 100,
 def psnr_from_sse(sse_total: float, n_values: int) -> float:
     """plotter.py:14-15 with mse_op of smoe.py:1053: 10*log10((2^p)^2 / (mean(diff^2)*(2^p)^2))."""
     return float(-10.0 * np.log10(sse_total / n_values))
+
+
+# --------------------------------------------------------------------------
+# shared-kernel image mode (SURVEY 8(f-1)): ONE global kernel set, per-batch kernel lists,
+# gradients accumulated over the batches of a pass, one Adam step per pass
+# --------------------------------------------------------------------------
+def global_batch_coords(image_shape: Sequence[int], batch_shape: Sequence[int], dtype=np.float32) -> np.ndarray:
+    """(NB, Nb, d) global pixel coordinates of every batch in sliding_window order
+    (smoe.py:18-35, 2412): linspace(0,1,size) per image axis, fed as float32."""
+    d = len(batch_shape)
+    axes = [np.linspace(0, 1, int(s)).astype(np.float32).astype(dtype) for s in image_shape]
+    grids = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1)                 # (*image, d)
+    g = [int(s) // int(b) for s, b in zip(image_shape, batch_shape)]
+    split = []
+    for gi, bi in zip(g, batch_shape):
+        split += [gi, int(bi)]
+    perm = list(range(0, 2 * d, 2)) + list(range(1, 2 * d, 2))
+    return grids.reshape(split + [d]).transpose(perm + [2 * d]).reshape(int(np.prod(g)), -1, d)
+
+
+def shared_init_params(image: np.ndarray, kernels_per_dim: Sequence[int], normalize_pis: bool = True):
+    """Smoe.__init__ without init_params for the whole image (smoe.py:260-262): parameters with a
+    leading axis of 1 (one model)."""
+    return init_params(image[None], kernels_per_dim, normalize_pis)
+
+
+def _bcast(p, NB):
+    return {k: np.broadcast_to(v, (NB,) + v.shape[1:]) for k, v in p.items()}
+
+
+def shared_pass(p, target, coords, lists, cfg: OracleConfig, dtype=np.float32, want_grads=False):
+    """One run_batched pass (smoe.py:1606-1793) in shared-kernel mode.  p: leading axis 1;
+    target (NB,Nb,C); coords (NB,Nb,d); lists (NB,K) bool.  Returns the per-batch forward dict plus
+    ``loss_val``/``mse_val`` (pixel-weighted means, smoe.py:1758-1759), ``lists_new`` (1763-1766)
+    and, with want_grads, ``grads`` = SUM over batches of the per-batch gradients (smoe.py:1150)."""
+    NB = target.shape[0]
+    f = forward(_bcast(p, NB), target, coords, lists, cfg, None, dtype, want_grads=want_grads)
+    f["loss_val"] = float(np.mean(f["loss"]))                       # equal-size batches
+    f["mse_val"] = float(np.mean(f["mse_op"]))
+    f["lists_new"] = f["active_new"]
+    if want_grads:
+        f["grads"] = {k: np.sum(v, axis=0, keepdims=True) for k, v in f["grads"].items()}
+    return f
+
+
+def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):
+    """update_kernel_list (smoe.py:2287-2365): per batch, probes = {min,max,mid}^d of the batch's
+    coordinates; list |= (pis>0) & any_probe(maha < 800)."""
+    T = dtype
+    NB, _, d = coords.shape
+    mins, maxs = coords.min(axis=1).astype(np.float64), coords.max(axis=1).astype(np.float64)
+    tt = np.stack([mins, maxs, (mins + maxs) / 2], axis=-1)                       # (NB,d,3)
+    A = _steering(p, T)[0]
+    mu = p["musX"].astype(T)[0]
+    out = lists.copy()
+    for b in range(NB):
+        probes = np.array(list(itertools.product(*tt[b]))).astype(np.float32).astype(T)
+        r = probes[None, :, :] - mu[:, None, :]
+        z = np.einsum("knl,klm->knm", r, A)
+        near = np.any(np.sum(z * z, axis=-1) < T(800), axis=1)
+        out[b] |= near & (p["pis"][0] > 0)
+    return out
+
+
+def shared_fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int = 100, ukl_iter=None,
+               dtype=np.float32):
+    """Smoe.train in shared-kernel mode (smoe.py:1485-1603): iteration-0 eval pass, per iteration a
+    train pass (prune lists) + one Adam step on the accumulated gradients, readmission every
+    ukl_iter, eval + best snapshot every val_iter."""
+    T = dtype
+    if ukl_iter is None:
+        ukl_iter = val_iter
+    NB = target.shape[0]
+    K = p["pis"].shape[1]
+    p = {k: v.astype(T) for k, v in p.items()}
+    state = new_adam_state(p)
+    lists = np.ones((NB, K), dtype=bool)                              # smoe.py:315
+    f0 = shared_pass(p, target, coords, lists, cfg, T)
+    lists = f0["lists_new"]
+    hist = {"iter": [0], "loss": [f0["loss_val"]], "mse": [f0["mse_val"]]}
+    best, best_loss = {k: v.copy() for k, v in p.items()}, f0["loss_val"]
+    train_losses = []
+    for i in range(1, n_iters + 1):
+        f = shared_pass(p, target, coords, lists, cfg, T, want_grads=True)
+        lists = f["lists_new"]
+        p = adam_step(p, f["grads"], state, cfg, T)
+        train_losses.append(f["loss_val"])
+        if i % ukl_iter == 0:
+            lists = shared_readmit(p, lists, coords, cfg, T)
+        if i % val_iter == 0:
+            fv = shared_pass(p, target, coords, lists, cfg, T)
+            lists = fv["lists_new"]
+            if fv["loss_val"] < best_loss:
+                best_loss, best = fv["loss_val"], {k: v.copy() for k, v in p.items()}
+            hist["iter"].append(i)
+            hist["loss"].append(fv["loss_val"])
+            hist["mse"].append(fv["mse_val"])
+    return p, state, {"lists": lists, "hist": hist, "best": best, "best_loss": best_loss,
+                      "train_losses": train_losses}

@@ -23,6 +23,9 @@ EXPORTS = (
     "smoe_create", "smoe_destroy", "smoe_is_supported", "smoe_get_coords", "smoe_forward",
     "smoe_fit", "smoe_update_kernel_list", "smoe_checkpoint_best", "smoe_reduce_scalars",
     "smoe_fit_variant", "smoe_fit_occupancy", "smoe_set_tiling", "smoe_last_error", "smoe_abi_version",
+    "smoe_shared_create", "smoe_shared_destroy", "smoe_shared_num_batches", "smoe_shared_list_words",
+    "smoe_shared_forward", "smoe_shared_accumulate", "smoe_shared_apply", "smoe_shared_grad_buffer",
+    "smoe_shared_fit", "smoe_shared_update_kernel_list",
 )
 
 
@@ -36,6 +39,18 @@ class SmoeConfig(C.Structure):
         ("lr_steer", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
         ("adam_eps", C.c_float), ("grad_clip", C.c_float), ("pis_l1", C.c_float),
         ("u_l1", C.c_float), ("start_pis", C.c_int32),
+    ]
+
+
+class SmoeSharedConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("dim", C.c_int32),
+        ("image_shape", C.c_int32 * 3), ("batch_shape", C.c_int32 * 3),
+        ("channels", C.c_int32), ("kernels", C.c_int32), ("precision", C.c_int32), ("margin", C.c_float),
+        ("use_determinant", C.c_int32), ("use_yuv", C.c_int32), ("train_pis", C.c_int32),
+        ("train_gammas", C.c_int32), ("train_musx", C.c_int32), ("lr_expert", C.c_float), ("lr_pis", C.c_float),
+        ("lr_steer", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("grad_clip", C.c_float), ("pis_l1", C.c_float), ("u_l1", C.c_float), ("start_pis", C.c_int32),
     ]
 
 
@@ -83,6 +98,16 @@ def load() -> C.CDLL:
     lib.smoe_fit_occupancy.argtypes = [vp, i32]
     lib.smoe_set_tiling.argtypes = [vp, i32]
     lib.smoe_last_error.restype = C.c_char_p
+    lib.smoe_shared_create.argtypes = [C.POINTER(vp), C.POINTER(SmoeSharedConfig)]
+    lib.smoe_shared_destroy.argtypes = [vp]
+    lib.smoe_shared_num_batches.argtypes = [vp]
+    lib.smoe_shared_list_words.argtypes = [vp]
+    lib.smoe_shared_forward.argtypes = [vp, i32, i32, fp, C.POINTER(SmoeParams), fp, fp, fp, fp, fp, i32, vp]
+    lib.smoe_shared_accumulate.argtypes = [vp, i32, i32, fp, C.POINTER(SmoeParams), fp, fp, fp, vp]
+    lib.smoe_shared_apply.argtypes = [vp, C.POINTER(SmoeParams), C.POINTER(SmoeAdamState), vp]
+    lib.smoe_shared_grad_buffer.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.smoe_shared_fit.argtypes = [vp, fp, C.POINTER(SmoeParams), C.POINTER(SmoeAdamState), i32, fp, fp, fp, vp]
+    lib.smoe_shared_update_kernel_list.argtypes = [vp, i32, i32, C.POINTER(SmoeParams), fp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("smoe_fit_variant", "smoe_last_error"):

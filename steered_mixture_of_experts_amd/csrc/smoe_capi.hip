@@ -311,3 +311,239 @@ int smoe_reduce_scalars(smoe_handle h, int32_t num_blocks, const float* loss, co
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// shared-kernel image mode
+// =================================================================================================
+struct smoe_shared_context {
+    smoe_shared_config cfg;
+    int NB, Nb, KW, PK;
+    int grid[SMOE_MAX_DIM];
+    int axis_off[SMOE_MAX_DIM];
+    float* d_axes;        // concatenated per-axis coordinate tables
+    float* d_probes;      // [NB][D][3]
+    double* d_racc;       // [K*PK + K]
+    smoe::KernelConsts kc;
+};
+
+namespace {
+
+void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
+    const smoe_shared_config& c = h->cfg;
+    a.axis_coords = h->d_axes;
+    for (int l = 0; l < SMOE_MAX_DIM; ++l) {
+        a.axis_off[l] = h->axis_off[l];
+        a.batch_shape[l] = (l < c.dim) ? c.batch_shape[l] : 1;
+        a.grid[l] = (l < c.dim) ? h->grid[l] : 1;
+    }
+    a.Nb = h->Nb; a.K = c.kernels; a.KW = h->KW;
+    a.kc = h->kc;
+    a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
+    a.reg_u = c.u_l1;
+    a.racc = h->d_racc;
+    a.nact = h->d_racc + (size_t)c.kernels * h->PK;
+}
+
+int check_range(const smoe_shared_context* h, int first, int count, const char* who) {
+    if (first < 0 || count < 0 || first + count > h->NB) return fail(SMOE_ERR_INVALID, std::string(who) + ": batch range out of bounds");
+    return SMOE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
+    if (!out || !cfg) return fail(SMOE_ERR_INVALID, "smoe_shared_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != SMOE_ABI_VERSION) return fail(SMOE_ERR_INVALID, "smoe_shared_create: abi_version mismatch");
+    if (cfg->dim < 2 || cfg->dim > SMOE_MAX_DIM) return fail(SMOE_ERR_INVALID, "smoe_shared_create: dim must be 2 or 3");
+    if (cfg->channels != 1 && cfg->channels != 3) return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: channels must be 1 or 3");
+    if (cfg->kernels < 1 || cfg->kernels > 8192) return fail(SMOE_ERR_INVALID, "smoe_shared_create: kernels must be 1..8192");
+    if (cfg->precision < 1 || cfg->precision > 16) return fail(SMOE_ERR_INVALID, "smoe_shared_create: precision must be 1..16");
+    long Nb = 1, NB = 1;
+    for (int l = 0; l < cfg->dim; ++l) {
+        if (cfg->batch_shape[l] < 1 || cfg->image_shape[l] < 1 || cfg->image_shape[l] % cfg->batch_shape[l] != 0)
+            return fail(SMOE_ERR_INVALID, "smoe_shared_create: Required BatchSize is not compatible to input dimensions");  // smoe.py:241
+        Nb *= cfg->batch_shape[l];
+        NB *= cfg->image_shape[l] / cfg->batch_shape[l];
+    }
+    if (!smoe::shared_supported(cfg->dim, cfg->channels, (int)Nb))
+        return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: batch too large (<= 2048 pixels for 1 channel, <= 1024 for 3)");
+    const int KW = (cfg->kernels + 31) / 32;
+    if (smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, KW) > 160u * 1024u)
+        return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: kernel list does not fit in LDS");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SMOE_ERR_NO_DEVICE, "smoe_shared_create: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SMOE_ERR_INVALID, "smoe_shared_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device), "hipSetDevice");
+    smoe_shared_context* h = new (std::nothrow) smoe_shared_context();
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_create: out of host memory");
+    h->cfg = *cfg;
+    h->NB = (int)NB; h->Nb = (int)Nb; h->KW = KW;
+    const int D = cfg->dim, C = cfg->channels;
+    h->PK = 1 + D + D * (D + 1) / 2 + C + D * C;
+    // global axis tables linspace(0,1,size) (smoe.py:2412) and per-batch probes (smoe.py:2322-2333)
+    std::vector<float> axes;
+    std::vector<std::vector<double>> axd(D);
+    for (int l = 0; l < SMOE_MAX_DIM; ++l) { h->grid[l] = 1; h->axis_off[l] = 0; }
+    for (int l = 0; l < D; ++l) {
+        h->grid[l] = cfg->image_shape[l] / cfg->batch_shape[l];
+        h->axis_off[l] = (int)axes.size();
+        const int n = cfg->image_shape[l];
+        axd[l].resize(n);
+        const double step = n > 1 ? 1.0 / (double)(n - 1) : 0.0;
+        for (int i = 0; i < n; ++i) axd[l][i] = (n > 1 && i == n - 1) ? 1.0 : (double)i * step;
+        for (int i = 0; i < n; ++i) axes.push_back((float)axd[l][i]);
+    }
+    std::vector<float> probes((size_t)NB * D * 3);
+    for (long b = 0; b < NB; ++b) {
+        long rem = b;
+        for (int l = D - 1; l >= 0; --l) {
+            const int o = (int)(rem % h->grid[l]) * cfg->batch_shape[l];
+            rem /= h->grid[l];
+            const double mn = axd[l][o], mx = axd[l][o + cfg->batch_shape[l] - 1];
+            probes[((size_t)b * D + l) * 3 + 0] = (float)mn;
+            probes[((size_t)b * D + l) * 3 + 1] = (float)mx;
+            probes[((size_t)b * D + l) * 3 + 2] = (float)((mn + mx) / 2.0);
+        }
+    }
+    const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
+    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr;
+    hipError_t e = hipMalloc(&h->d_axes, sizeof(float) * axes.size());
+    if (e == hipSuccess) e = hipMalloc(&h->d_probes, sizeof(float) * probes.size());
+    if (e == hipSuccess) e = hipMalloc(&h->d_racc, sizeof(double) * nacc);
+    if (e == hipSuccess) e = hipMemcpy(h->d_axes, axes.data(), sizeof(float) * axes.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * probes.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(h->d_racc, 0, sizeof(double) * nacc);
+    if (e != hipSuccess) {
+        if (h->d_axes) (void)hipFree(h->d_axes);
+        if (h->d_probes) (void)hipFree(h->d_probes);
+        if (h->d_racc) (void)hipFree(h->d_racc);
+        delete h;
+        return fail_hip(e, "smoe_shared_create: workspace");
+    }
+    smoe::KernelConsts& kc = h->kc;
+    const double two_p = std::ldexp(1.0, cfg->precision);
+    kc.tau = (float)(0.5 * 1.0 / two_p);
+    kc.epsm = (float)((double)cfg->margin * 1.0 / two_p);
+    const float levels = (float)(two_p - 1.0);
+    kc.scale = 1.0f / levels;
+    kc.inv_scale = 1.0f / kc.scale;
+    kc.nudged_max = fminf(1.0f, levels * kc.scale);
+    for (int c = 0; c < SMOE_MAX_CHANNELS; ++c) kc.cw[c] = 0.0f;
+    for (int c = 0; c < C; ++c) {                                   // per-BATCH means (smoe.py:934-937)
+        if (cfg->use_yuv) kc.cw[c] = (float)(((c == 0) ? 6.0 / 8.0 : 1.0 / 8.0) / (double)Nb);
+        else kc.cw[c] = (float)(1.0 / ((double)Nb * C));
+    }
+    kc.n_dis = (float)std::sqrt(std::pow(2.0 * M_PI, (double)D));
+    kc.use_det = cfg->use_determinant ? 1 : 0;
+    kc.train_gammas = cfg->train_gammas ? 1 : 0;
+    *out = h;
+    return SMOE_OK;
+}
+
+int smoe_shared_destroy(smoe_shared_handle h) {
+    if (!h) return SMOE_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->d_axes) (void)hipFree(h->d_axes);
+    if (h->d_probes) (void)hipFree(h->d_probes);
+    if (h->d_racc) (void)hipFree(h->d_racc);
+    delete h;
+    return SMOE_OK;
+}
+
+int smoe_shared_num_batches(smoe_shared_handle h) { return h ? h->NB : fail(SMOE_ERR_INVALID, "null handle"); }
+int smoe_shared_list_words(smoe_shared_handle h) { return h ? h->KW : fail(SMOE_ERR_INVALID, "null handle"); }
+
+int smoe_shared_grad_buffer(smoe_shared_handle h, double** dev_ptr, int64_t* count) {
+    if (!h || !dev_ptr || !count) return fail(SMOE_ERR_INVALID, "smoe_shared_grad_buffer: null argument");
+    *dev_ptr = h->d_racc;
+    *count = (int64_t)h->cfg.kernels * h->PK + h->cfg.kernels;
+    return SMOE_OK;
+}
+
+int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
+                        const smoe_params* p, float* recon, int32_t* argmax, float* loss, float* sse,
+                        uint32_t* lists, int32_t update_lists, void* stream) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_forward: null handle");
+    int rc = check_range(h, first_batch, num_batches, "smoe_shared_forward");
+    if (rc) return rc;
+    if (num_batches == 0) return SMOE_OK;
+    if (!target || !params_ok(p) || !lists) return fail(SMOE_ERR_INVALID, "smoe_shared_forward: target, params and lists are required");
+    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+    smoe::SharedArgs a;
+    fill_shared_args(h, a);
+    a.target = target; a.p = *p; a.lists = lists; a.b0 = first_batch; a.NB = num_batches;
+    a.loss = loss; a.sse = sse; a.recon = recon; a.argmax = argmax; a.update_lists = update_lists;
+    HIP_TRY(smoe::launch_shared_pass(a, h->cfg.dim, h->cfg.channels, false, (hipStream_t)stream), "smoe_shared_forward launch");
+    return SMOE_OK;
+}
+
+int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
+                           const smoe_params* p, float* loss, float* sse, uint32_t* lists, void* stream) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_accumulate: null handle");
+    int rc = check_range(h, first_batch, num_batches, "smoe_shared_accumulate");
+    if (rc) return rc;
+    if (num_batches == 0) return SMOE_OK;
+    if (!target || !params_ok(p) || !lists) return fail(SMOE_ERR_INVALID, "smoe_shared_accumulate: target, params and lists are required");
+    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+    smoe::SharedArgs a;
+    fill_shared_args(h, a);
+    a.target = target; a.p = *p; a.lists = lists; a.b0 = first_batch; a.NB = num_batches;
+    a.loss = loss; a.sse = sse; a.recon = nullptr; a.argmax = nullptr; a.update_lists = 1;
+    HIP_TRY(smoe::launch_shared_pass(a, h->cfg.dim, h->cfg.channels, true, (hipStream_t)stream), "smoe_shared_accumulate launch");
+    return SMOE_OK;
+}
+
+int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: null handle");
+    if (!params_ok(p) || !s || !params_ok(&s->m) || !params_ok(&s->v)) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: params and adam state are required");
+    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+    const smoe_shared_config& c = h->cfg;
+    smoe::SharedAdamArgs a;
+    a.p = *p; a.m = s->m; a.v = s->v;
+    a.racc = h->d_racc; a.nact = h->d_racc + (size_t)c.kernels * h->PK; a.K = c.kernels;
+    a.b1p = s->beta1_power; a.b2p = s->beta2_power; a.beta1 = c.beta1; a.beta2 = c.beta2; a.eps = c.adam_eps;
+    a.clip = c.grad_clip;
+    a.lr_expert = c.lr_expert; a.lr_pis = c.lr_pis; a.lr_steer = c.lr_steer;
+    a.train_pis = c.train_pis; a.train_musx = c.train_musx; a.train_gammas = c.train_gammas; a.use_det = c.use_determinant;
+    a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
+    a.reg_u = c.u_l1;
+    HIP_TRY(smoe::launch_shared_adam(a, c.dim, c.channels, (hipStream_t)stream), "smoe_shared_apply launch");
+    s->beta1_power *= c.beta1;
+    s->beta2_power *= c.beta2;
+    s->step += 1;
+    return SMOE_OK;
+}
+
+int smoe_shared_fit(smoe_shared_handle h, const float* target, smoe_params* p, smoe_adam_state* s, int32_t n_iters,
+                    float* loss_last, float* sse_last, uint32_t* lists, void* stream) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_fit: null handle");
+    if (n_iters < 0) return fail(SMOE_ERR_INVALID, "smoe_shared_fit: negative n_iters");
+    for (int i = 0; i < n_iters; ++i) {
+        int rc = smoe_shared_accumulate(h, 0, h->NB, target, p, loss_last, sse_last, lists, stream);
+        if (rc) return rc;
+        rc = smoe_shared_apply(h, p, s, stream);
+        if (rc) return rc;
+    }
+    return SMOE_OK;
+}
+
+int smoe_shared_update_kernel_list(smoe_shared_handle h, int32_t first_batch, int32_t num_batches,
+                                   const smoe_params* p, uint32_t* lists, void* stream) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_update_kernel_list: null handle");
+    int rc = check_range(h, first_batch, num_batches, "smoe_shared_update_kernel_list");
+    if (rc) return rc;
+    if (num_batches == 0) return SMOE_OK;
+    if (!params_ok(p) || !lists) return fail(SMOE_ERR_INVALID, "smoe_shared_update_kernel_list: params and lists are required");
+    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+    smoe::SharedReadmitArgs a;
+    a.p = *p; a.lists = lists; a.probes = h->d_probes + (size_t)first_batch * h->cfg.dim * 3;
+    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW;
+    HIP_TRY(smoe::launch_shared_readmit(a, h->cfg.dim, (hipStream_t)stream), "smoe_shared_update_kernel_list launch");
+    return SMOE_OK;
+}
+
+}  // extern "C"

@@ -91,6 +91,51 @@ struct Variant {
     int (*fit_waves_per_cu)(int N, bool has_lw);
 };
 
+// ---- shared-kernel image mode (smoe_shared.hip) ----------------------------------------------
+struct SharedArgs {
+    const float* target;      // [nb][C][Nb] of the batches [b0, b0+nb)
+    smoe_params p;            // global kernels [K,...]
+    const float* axis_coords; // per-axis global coordinate tables, concatenated
+    int axis_off[SMOE_MAX_DIM];
+    int batch_shape[SMOE_MAX_DIM];
+    int grid[SMOE_MAX_DIM];   // batches per axis
+    uint32_t* lists;          // [nb][KW] kernel-list bitmaps
+    int b0, NB, Nb, K, KW;    // NB = batches in this launch
+    float* loss;              // [nb] or null
+    float* sse;               // [nb] or null
+    float* recon;             // [nb][C][Nb] or null
+    int32_t* argmax;          // [nb][Nb] or null
+    double* racc;             // [K][PK] raw gradient sums (train)
+    double* nact;             // [K] number of batches that listed the kernel (train, for the l1 terms)
+    int update_lists;
+    KernelConsts kc;
+    float reg_pi, reg_u;
+};
+
+struct SharedAdamArgs {
+    smoe_params p, m, v;
+    double* racc;
+    double* nact;
+    int K;
+    float b1p, b2p, beta1, beta2, eps, clip;
+    float lr_expert, lr_pis, lr_steer;
+    int train_pis, train_musx, train_gammas, use_det;
+    float reg_pi, reg_u;
+};
+
+struct SharedReadmitArgs {
+    smoe_params p;
+    uint32_t* lists;          // [nb][KW]
+    const float* probes;      // [nb][D][3]
+    int NB, K, KW;
+};
+
+size_t shared_lds_bytes(int D, int C, int K, int KW);
+bool shared_supported(int D, int C, int Nb);
+hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st);
+hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st);
+hipError_t launch_shared_readmit(const SharedReadmitArgs& a, int D, hipStream_t st);
+
 const Variant* variants(int* count);
 hipError_t launch_readmit(const ReadmitArgs& a, int D, hipStream_t st);
 hipError_t launch_best(const BestArgs& a, hipStream_t st);

@@ -1,0 +1,533 @@
+// smoe_shared.hip -- shared-kernel image mode: ONE global set of K kernels, the
+// image is cut into batches (smoe.py:18-35), every batch evaluates only the kernels on its
+// kernel list (smoe.py:738-753), gradients of all batches of a pass are accumulated
+// (smoe.py:1148-1150) and ONE Adam step follows (smoe.py:1788).
+//
+// One 256-thread workgroup per batch, PXL pixels per lane held in registers.  The batch's active
+// kernels are compacted into an LDS list and staged (with derived quantities) through LDS in chunks;
+// three sweeps over the list per pass: (A) gate normaliser S, (B) masked gate / experts / blend /
+// influence flags, (C) reverse pass with per-kernel raw sums reduced across the wavefront and
+// added to fp64 global accumulators (order effects of the atomics stay below fp32 resolution).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smoe_device.h"
+
+namespace smoe {
+
+namespace {
+
+constexpr int SH_THREADS = 256;
+constexpr int SH_KC = 64;                 // kernels staged per LDS chunk
+constexpr float SQ = 0.84932180028801904272f;       // sqrt(0.5*log2(e)), see smoe_kernels.hip
+constexpr float INV_SQ = 1.17740022503374817543f;
+
+constexpr int tri(int l, int m) { return l * (l + 1) / 2 + m; }
+
+template <int D, int C>
+struct SL {                                // staged (derived) record of one kernel in LDS
+    static constexpr int TRI = D * (D + 1) / 2;
+    static constexpr int O_AS = 0;         // A' = SQ*A lower triangle
+    static constexpr int O_CZ = TRI;       // c = A'^T mu
+    static constexpr int O_COEF = TRI + D;
+    static constexpr int O_NU = O_COEF + 1;
+    static constexpr int O_GA = O_NU + C;  // gamma[l][c]
+    static constexpr int SP = O_GA + D * C;
+    // raw accumulator record (per kernel): su | suz[D] | sxz[TRI] | swg[C] | swgx[D][C]
+    static constexpr int R_SU = 0;
+    static constexpr int R_SUZ = 1;
+    static constexpr int R_SXZ = 1 + D;
+    static constexpr int R_SWG = R_SXZ + TRI;
+    static constexpr int R_SWGX = R_SWG + C;
+    static constexpr int PK = R_SWGX + D * C;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// one pass over all batches
+// ---------------------------------------------------------------------------------------------
+template <int D, int C, int PXL, bool TRAIN>
+__global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
+    using L = SL<D, C>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;                 // batch index inside this launch (buffers are launch-local)
+    const int Nb = a.Nb;
+    const int K = a.K;
+
+    // LDS carve-up
+    int* s_list = reinterpret_cast<int*>(lds);                       // [K] compacted active kernel ids
+    float* s_par = lds + a.K;                                        // [SH_KC][SP]
+    float* s_acc = s_par + SH_KC * L::SP;                            // [4 waves][SH_KC][PK] (no atomics: fixed summation order)
+    int* s_flag = reinterpret_cast<int*>(s_acc + 4 * SH_KC * L::PK); // [K] influence flags (by list position)
+    float* s_red = reinterpret_cast<float*>(s_flag + a.K);           // [8] block reductions
+    int* s_cnt = reinterpret_cast<int*>(s_red + 8);                  // [8]
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_cnt + 8);       // [KW]
+
+    // ---- 0. compact the batch's kernel list: listed & pis > 0 (smoe.py:480,738) ----------------
+    const uint32_t* bits = a.lists + (size_t)b * a.KW;
+    if (tid == 0) s_cnt[0] = 0;
+    __syncthreads();
+    for (int base = 0; base < K; base += SH_THREADS) {
+        const int k = base + tid;
+        bool act = false;
+        if (k < K) act = ((bits[k >> 5] >> (k & 31)) & 1u) && (a.p.pis[k] > 0.0f);
+        const unsigned long long m = __ballot(act);
+        if (lane == 0) s_cnt[1 + wave] = __popcll(m);
+        __syncthreads();
+        int off = s_cnt[0];
+        for (int w = 0; w < wave; ++w) off += s_cnt[1 + w];
+        if (act) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+        if (tid == 0) s_cnt[0] += s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4];
+        __syncthreads();
+    }
+    const int Kact = s_cnt[0];
+    for (int i = tid; i < Kact; i += SH_THREADS) s_flag[i] = 0;
+
+    // ---- 1. this lane's pixels: global coordinates (smoe.py:2412) and targets --------------------
+    int bo[D];                       // batch origin per axis (sliding_window order: last axis fastest)
+    {
+        int rem = a.b0 + b;           // global batch index -> position in the image
+#pragma unroll
+        for (int l = D - 1; l >= 0; --l) {
+            bo[l] = (rem % a.grid[l]) * a.batch_shape[l];
+            rem /= a.grid[l];
+        }
+    }
+    float x[PXL][D], t[PXL][C];
+    bool pv[PXL];
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) {
+        const int n = p * SH_THREADS + tid;
+        pv[p] = n < Nb;
+        int rem = pv[p] ? n : 0;
+#pragma unroll
+        for (int l = D - 1; l >= 0; --l) {
+            const int idx = rem % a.batch_shape[l];
+            rem /= a.batch_shape[l];
+            x[p][l] = a.axis_coords[a.axis_off[l] + bo[l] + idx];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) t[p][c] = a.target[((size_t)b * C + c) * Nb + (pv[p] ? n : 0)];
+    }
+
+    // stage chunk [c0, c0+n) of the active list into LDS (derived quantities, smoe.py:732-733,809-819)
+    auto stage = [&](int c0, int n) {
+        __syncthreads();
+        if (tid < n) {
+            const int k = s_list[c0 + tid];
+            float* r = s_par + tid * L::SP;
+            float det = 1.0f;
+            float A[D][D];
+#pragma unroll
+            for (int l = 0; l < D; ++l)
+#pragma unroll
+                for (int m = 0; m <= l; ++m) {
+                    A[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m];
+                    if (l == m) det *= A[l][m];
+                    r[L::O_AS + tri(l, m)] = SQ * A[l][m];
+                }
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float cz = 0.0f;
+#pragma unroll
+                for (int l = m; l < D; ++l) cz = fmaf(a.p.musX[(size_t)k * D + l], SQ * A[l][m], cz);
+                r[L::O_CZ + m] = cz;
+            }
+            const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
+            r[L::O_COEF] = nq * a.p.pis[k];
+#pragma unroll
+            for (int c = 0; c < C; ++c) r[L::O_NU + c] = a.p.nu_e[(size_t)k * C + c];
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) r[L::O_GA + i] = a.kc.train_gammas ? a.p.gamma_e[(size_t)k * D * C + i] : 0.0f;
+        }
+        __syncthreads();
+    };
+
+    // g_k(x) * 1 and z' for one pixel
+    auto gate = [&](const float* r, const float (&xx)[D], float (&z)[D]) -> float {
+        float maha = 0.0f;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float zz = -r[L::O_CZ + m];
+#pragma unroll
+            for (int l = D - 1; l >= m; --l) zz = fmaf(xx[l], r[L::O_AS + tri(l, m)], zz);
+            z[m] = zz;
+            maha = (m == 0) ? zz * zz : fmaf(zz, zz, maha);
+        }
+        return r[L::O_COEF] * fexp2(-maha);
+    };
+
+    // ---- 2. sweep A: gate normaliser (smoe.py:819-821) ---------------------------------------------
+    float S[PXL];
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) S[p] = 0.0f;
+    for (int c0 = 0; c0 < Kact; c0 += SH_KC) {
+        const int n = min(SH_KC, Kact - c0);
+        stage(c0, n);
+        for (int kk = 0; kk < n; ++kk) {
+            const float* r = s_par + kk * L::SP;
+#pragma unroll
+            for (int p = 0; p < PXL; ++p) {
+                float z[D];
+                S[p] += gate(r, x[p], z);
+            }
+        }
+    }
+    float inv[PXL];
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) inv[p] = frcp(fmaxf(S[p], 10e-12f));
+
+    // ---- 3. sweep B: masked gate, experts, blend, influence, argmax (smoe.py:823-848) ---------------
+    float y[PXL][C];
+    float best[PXL];
+    int arg[PXL];
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) {
+        best[p] = 0.0f;
+        arg[p] = -1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) y[p][c] = 0.0f;
+    }
+    for (int c0 = 0; c0 < Kact; c0 += SH_KC) {
+        const int n = min(SH_KC, Kact - c0);
+        stage(c0, n);
+        for (int kk = 0; kk < n; ++kk) {
+            const float* r = s_par + kk * L::SP;
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < PXL; ++p) {
+                float z[D];
+                const float w = gate(r, x[p], z) * inv[p];
+                const float wt = (pv[p] && w > a.kc.tau) ? w : 0.0f;
+                any = any || (wt > 0.0f);
+                if (wt > best[p]) { best[p] = wt; arg[p] = s_list[c0 + kk]; }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    float ee = r[L::O_NU + c];
+#pragma unroll
+                    for (int l = 0; l < D; ++l) ee = fmaf(r[L::O_GA + l * C + c], x[p][l], ee);
+                    y[p][c] = fmaf(wt, ee, y[p][c]);
+                }
+            }
+            if (__ballot(any) != 0ull && lane == 0) s_flag[c0 + kk] = 1;       // smoe.py:829
+        }
+    }
+
+    // ---- 4. clip + fake quant, loss, dL/dy (smoe.py:857,899,905-937) ----------------------------------
+    float Gc[PXL][C], dot[PXL];
+    float loss_part = 0.0f, sse_part = 0.0f;
+#pragma unroll
+    for (int p = 0; p < PXL; ++p) {
+        dot[p] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float yc = __builtin_amdgcn_fmed3f(y[p][c], 0.0f, a.kc.nudged_max);
+            const float q = floorf(fmaf(yc, a.kc.inv_scale, 0.5f)) * a.kc.scale;
+            const float diff = q - t[p][c];
+            const float ad = fabsf(diff) - a.kc.epsm;
+            if (pv[p]) {
+                sse_part = fmaf(diff, diff, sse_part);
+                loss_part = fmaf(a.kc.cw[c], ad * ad, loss_part);
+                if (a.recon != nullptr) a.recon[((size_t)b * C + c) * Nb + p * SH_THREADS + tid] = q;
+            }
+            const float sg = __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -1.0f, 1.0f);
+            const float gm = (a.kc.cw[c] + a.kc.cw[c]) * (ad * sg);
+            Gc[p][c] = (pv[p] && yc == y[p][c]) ? gm : 0.0f;
+            dot[p] = fmaf(Gc[p][c], y[p][c], dot[p]);
+        }
+        dot[p] = (S[p] > 10e-12f) ? dot[p] : 0.0f;
+    }
+
+    // ---- 5. sweep C: reverse pass, raw sums per kernel (smoe.py:1148-1150) ---------
+    if (TRAIN) {
+        for (int c0 = 0; c0 < Kact; c0 += SH_KC) {
+            const int n = min(SH_KC, Kact - c0);
+            stage(c0, n);
+            for (int kk = 0; kk < n; ++kk) {
+                const float* r = s_par + kk * L::SP;
+                float acc[L::PK];
+#pragma unroll
+                for (int j = 0; j < L::PK; ++j) acc[j] = 0.0f;
+#pragma unroll
+                for (int p = 0; p < PXL; ++p) {
+                    float z[D];
+                    const float w = gate(r, x[p], z) * inv[p];
+                    const float wt = (pv[p] && w > a.kc.tau) ? w : 0.0f;
+                    float eg = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float ee = r[L::O_NU + c];
+#pragma unroll
+                        for (int l = 0; l < D; ++l) ee = fmaf(r[L::O_GA + l * C + c], x[p][l], ee);
+                        eg = fmaf(ee, Gc[p][c], eg);
+                        const float wg = wt * Gc[p][c];
+                        acc[L::R_SWG + c] += wg;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) acc[L::R_SWGX + l * C + c] = fmaf(wg, x[p][l], acc[L::R_SWGX + l * C + c]);
+                    }
+                    const float u = pv[p] ? fmaf(wt, eg, -(w * dot[p])) : 0.0f;
+                    acc[L::R_SU] += u;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        const float uz = u * z[m];
+                        acc[L::R_SUZ + m] += uz;
+#pragma unroll
+                        for (int l = m; l < D; ++l) acc[L::R_SXZ + tri(l, m)] = fmaf(x[p][l], uz, acc[L::R_SXZ + tri(l, m)]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < L::PK; ++j) {
+                    const float v = wave_sum(acc[j]);
+                    if (lane == 0) s_acc[(wave * SH_KC + kk) * L::PK + j] = v;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < n * L::PK; i += SH_THREADS) {
+                const int kk = i / L::PK;
+                const int j = i - kk * L::PK;
+                const float v = (s_acc[i] + s_acc[SH_KC * L::PK + i]) + (s_acc[2 * SH_KC * L::PK + i] + s_acc[3 * SH_KC * L::PK + i]);
+                atomicAdd(&a.racc[(size_t)s_list[c0 + kk] * L::PK + j], (double)v);
+            }
+            if (a.nact != nullptr)
+                for (int i = tid; i < n; i += SH_THREADS) atomicAdd(&a.nact[s_list[c0 + i]], 1.0);
+        }
+    }
+
+    // ---- 6. per-batch scalars, kernel-list prune, argmax fix-up ------------------------------------
+    loss_part = wave_sum(loss_part);
+    sse_part = wave_sum(sse_part);
+    __syncthreads();
+    if (lane == 0) { s_red[wave] = loss_part; s_red[4 + wave] = sse_part; }
+    for (int i = tid; i < a.KW; i += SH_THREADS) s_bits[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < Kact; i += SH_THREADS)
+        if (s_flag[i]) atomicOr(&s_bits[s_list[i] >> 5], 1u << (s_list[i] & 31));
+    __syncthreads();
+    if (tid == 0) {
+        float lossv = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {                    // smoe.py:1027,1044 over the batch's active kernels
+            for (int i = 0; i < Kact; ++i) {
+                const int k = s_list[i];
+                lossv += a.reg_pi * a.p.pis[k];
+                for (int l = 0; l < D; ++l) lossv += a.reg_u * a.p.A_diagonal[((size_t)k * D + l) * D + l];
+            }
+        }
+        if (a.loss != nullptr) a.loss[b] = lossv;
+        if (a.sse != nullptr) a.sse[b] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    }
+    if (a.argmax != nullptr) {
+        int first = 0;                                                // smoe.py:1713-1716
+        for (int w = 0; w < a.KW; ++w)
+            if (s_bits[w]) { first = w * 32 + (__ffs(s_bits[w]) - 1); break; }
+#pragma unroll
+        for (int p = 0; p < PXL; ++p)
+            if (pv[p]) a.argmax[(size_t)b * Nb + p * SH_THREADS + tid] = (arg[p] >= 0) ? arg[p] : first;
+    }
+    if (a.update_lists)                                               // smoe.py:1763-1766
+        for (int i = tid; i < a.KW; i += SH_THREADS) a.lists[(size_t)b * a.KW + i] = s_bits[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// one Adam step on the accumulated gradients (train_op, smoe.py:1788,1173-1193); clears the
+// accumulators for the next pass (zero_op, smoe.py:1613)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_apply(float* var, float* m, float* v, float g, float lr, const SharedAdamArgs& a) {
+    if (lr == 0.0f) return;
+    if (a.clip > 0.0f) g = fminf(fmaxf(g, -a.clip), a.clip);
+    const float alpha = lr * sqrtf(1.0f - a.b2p) / (1.0f - a.b1p);
+    const float m2 = *m + (g - *m) * (1.0f - a.beta1);
+    const float v2 = *v + (g * g - *v) * (1.0f - a.beta2);
+    *m = m2;
+    *v = v2;
+    *var = *var - (m2 * alpha) / (sqrtf(v2) + a.eps);
+}
+
+template <int D, int C>
+__global__ void shared_adam_kernel(SharedAdamArgs a) {
+    using L = SL<D, C>;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.K) return;
+    double* rk = a.racc + (size_t)k * L::PK;
+    float r[L::PK];
+#pragma unroll
+    for (int j = 0; j < L::PK; ++j) { r[j] = (float)rk[j]; rk[j] = 0.0; }
+    const float nact = a.nact ? (float)a.nact[k] : 0.0f;
+    if (a.nact) a.nact[k] = 0.0;
+    const float pi = a.p.pis[k];
+    float A[D][D], mu[D];
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+        mu[l] = a.p.musX[(size_t)k * D + l];
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+            A[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+    }
+    const float su = r[L::R_SU];
+    float suz[D];
+#pragma unroll
+    for (int m = 0; m < D; ++m) suz[m] = r[L::R_SUZ + m] * INV_SQ;
+    // pis (optimizer2)
+    if (a.train_pis) {
+        const float g = (pi > 0.0f ? su / pi : 0.0f) + nact * a.reg_pi;
+        adam_apply(&a.p.pis[k], &a.m.pis[k], &a.v.pis[k], g, a.lr_pis, a);
+    }
+    // musX (optimizer1)
+    if (a.train_musx) {
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            float g = 0.0f;
+#pragma unroll
+            for (int m = 0; m <= l; ++m) g = fmaf(A[l][m], suz[m], g);
+            const size_t o = (size_t)k * D + l;
+            adam_apply(&a.p.musX[o], &a.m.musX[o], &a.v.musX[o], g, a.lr_expert, a);
+        }
+    }
+    // steering (optimizer3)
+#pragma unroll
+    for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int m = 0; m <= l; ++m) {
+            float g = fmaf(mu[l], suz[m], -(r[L::R_SXZ + tri(l, m)] * INV_SQ));
+            const size_t o = ((size_t)k * D + l) * D + m;
+            if (l == m) {
+                if (a.use_det) g += su / A[l][l];
+                g += nact * a.reg_u;
+                adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], g, a.lr_steer, a);
+            } else {
+                adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], g, a.lr_steer, a);
+            }
+        }
+    // experts (optimizer1)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t o = (size_t)k * C + c;
+        adam_apply(&a.p.nu_e[o], &a.m.nu_e[o], &a.v.nu_e[o], r[L::R_SWG + c], a.lr_expert, a);
+    }
+    if (a.train_gammas) {
+#pragma unroll
+        for (int i = 0; i < D * C; ++i) {
+            const size_t o = (size_t)k * D * C + i;
+            adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], r[L::R_SWGX + i], a.lr_expert, a);
+        }
+    }
+}
+
+// update_kernel_list (smoe.py:2287-2365): probes = {min,max,mid}^d of the batch's coordinates
+template <int D>
+__global__ void shared_readmit_kernel(SharedReadmitArgs a) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)a.NB * a.K) return;
+    const int b = (int)(t / a.K);
+    const int k = (int)(t - (long)b * a.K);
+    if (!(a.p.pis[k] > 0.0f)) return;
+    float A[D][D];
+#pragma unroll
+    for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+            A[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+    int nprobe = 1;
+#pragma unroll
+    for (int l = 0; l < D; ++l) nprobe *= 3;
+    bool near = false;
+    for (int q = 0; q < nprobe; ++q) {
+        float r[D];
+        int rem = q;
+#pragma unroll
+        for (int l = D - 1; l >= 0; --l) {
+            const int sel = rem % 3;
+            rem /= 3;
+            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - a.p.musX[(size_t)k * D + l];
+        }
+        float maha = 0.0f;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float zz = 0.0f;
+#pragma unroll
+            for (int l = m; l < D; ++l) zz = fmaf(r[l], A[l][m], zz);
+            maha = fmaf(zz, zz, maha);
+        }
+        near = near || (maha < 800.0f);
+    }
+    if (near) atomicOr(&a.lists[(size_t)b * a.KW + (k >> 5)], 1u << (k & 31));
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+size_t shared_lds_bytes(int D, int C, int K, int KW) {
+    const int TRI = D * (D + 1) / 2;
+    const int SP = TRI + D + 1 + C + D * C;
+    const int PK = 1 + D + TRI + C + D * C;
+    return sizeof(float) * ((size_t)K + SH_KC * SP + 4 * SH_KC * PK + K + 8 + 8 + KW);
+}
+
+template <int D, int C, int PXL>
+static hipError_t launch_pass_t(const SharedArgs& a, bool train, hipStream_t st) {
+    const size_t shm = shared_lds_bytes(D, C, a.K, a.KW);
+    auto kern = train ? shared_pass_kernel<D, C, PXL, true> : shared_pass_kernel<D, C, PXL, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.NB), dim3(SH_THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C>
+static hipError_t launch_pass_dc(const SharedArgs& a, bool train, hipStream_t st) {
+    const int pxl = (a.Nb + SH_THREADS - 1) / SH_THREADS;
+    if (pxl <= 1) return launch_pass_t<D, C, 1>(a, train, st);
+    if (pxl <= 2) return launch_pass_t<D, C, 2>(a, train, st);
+    if (pxl <= 4) return launch_pass_t<D, C, 4>(a, train, st);
+    if (C == 1 && pxl <= 8) return launch_pass_t<D, 1, 8>(a, train, st);
+    return hipErrorInvalidValue;
+}
+
+bool shared_supported(int D, int C, int Nb) {
+    if (!((D == 2 || D == 3) && (C == 1 || C == 3))) return false;
+    const int pxl = (Nb + SH_THREADS - 1) / SH_THREADS;
+    return pxl <= (C == 1 ? 8 : 4);
+}
+
+hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st) {
+    if (D == 2 && C == 1) return launch_pass_dc<2, 1>(a, train, st);
+    if (D == 2 && C == 3) return launch_pass_dc<2, 3>(a, train, st);
+    if (D == 3 && C == 1) return launch_pass_dc<3, 1>(a, train, st);
+    if (D == 3 && C == 3) return launch_pass_dc<3, 3>(a, train, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st) {
+    const int threads = 128;
+    const int grid = (a.K + threads - 1) / threads;
+    if (D == 2 && C == 1) hipLaunchKernelGGL((shared_adam_kernel<2, 1>), dim3(grid), dim3(threads), 0, st, a);
+    else if (D == 2 && C == 3) hipLaunchKernelGGL((shared_adam_kernel<2, 3>), dim3(grid), dim3(threads), 0, st, a);
+    else if (D == 3 && C == 1) hipLaunchKernelGGL((shared_adam_kernel<3, 1>), dim3(grid), dim3(threads), 0, st, a);
+    else if (D == 3 && C == 3) hipLaunchKernelGGL((shared_adam_kernel<3, 3>), dim3(grid), dim3(threads), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_shared_readmit(const SharedReadmitArgs& a, int D, hipStream_t st) {
+    const int threads = 256;
+    const long total = (long)a.NB * a.K;
+    const int grid = (int)((total + threads - 1) / threads);
+    if (D == 2) hipLaunchKernelGGL(shared_readmit_kernel<2>, dim3(grid), dim3(threads), 0, st, a);
+    else hipLaunchKernelGGL(shared_readmit_kernel<3>, dim3(grid), dim3(threads), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace smoe

@@ -225,3 +225,161 @@ class BlockEngine:
         _lib.check(self.lib.smoe_reduce_scalars(self._h, B, _ptr(loss), _ptr(sse), _ptr(active), _ptr(out),
                                                 self._stream()))
         return out
+
+
+# =====================================================================================================
+# shared-kernel image mode
+# =====================================================================================================
+@dataclasses.dataclass
+class SharedConfig:
+    """Mirror of ``smoe_shared_config``: ONE global kernel set over the image, batches of
+    ``batch_shape`` pixels with per-batch kernel lists."""
+    image_shape: Sequence[int]
+    batch_shape: Sequence[int]
+    channels: int
+    kernels: int
+    precision: int = 8
+    margin: float = 0.5
+    use_determinant: bool = True
+    use_yuv: bool = False
+    train_pis: bool = True
+    train_gammas: bool = True
+    train_musx: bool = True
+    lr_expert: float = 1e-3
+    lr_pis: float = 1e-5
+    lr_steer: float = 1.0
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1e-8
+    grad_clip: float = 0.0
+    pis_l1: float = 0.0
+    u_l1: float = 0.0
+    start_pis: int = 0
+
+    @property
+    def dim(self) -> int:
+        return len(self.image_shape)
+
+
+class SharedEngine:
+    """Host wrapper of the smoe_shared_* entry points.  Parameters: dict of contiguous float32
+    device tensors in the get_params() layout with leading K (no block axis)."""
+
+    def __init__(self, cfg: SharedConfig, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("SharedEngine needs a HIP device; this package has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.cfg = cfg
+        c = _lib.SmoeSharedConfig()
+        c.abi_version, c.device, c.dim = _lib.SMOE_ABI_VERSION, self.device.index or 0, cfg.dim
+        for i in range(3):
+            c.image_shape[i] = int(cfg.image_shape[i]) if i < cfg.dim else 1
+            c.batch_shape[i] = int(cfg.batch_shape[i]) if i < cfg.dim else 1
+        c.channels, c.kernels, c.precision, c.margin = cfg.channels, cfg.kernels, cfg.precision, cfg.margin
+        c.use_determinant, c.use_yuv = int(cfg.use_determinant), int(cfg.use_yuv)
+        c.train_pis, c.train_gammas, c.train_musx = int(cfg.train_pis), int(cfg.train_gammas), int(cfg.train_musx)
+        c.lr_expert, c.lr_pis, c.lr_steer = cfg.lr_expert, cfg.lr_pis, cfg.lr_steer
+        c.beta1, c.beta2, c.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
+        c.grad_clip, c.pis_l1, c.u_l1 = cfg.grad_clip or 0.0, cfg.pis_l1, cfg.u_l1
+        c.start_pis = cfg.start_pis or cfg.kernels
+        self._h = C.c_void_p()
+        _lib.check(self.lib.smoe_shared_create(C.byref(self._h), C.byref(c)))
+        self.num_batches = int(self.lib.smoe_shared_num_batches(self._h))
+        self.list_words = int(self.lib.smoe_shared_list_words(self._h))
+        self.batch_pixels = 1
+        for b in cfg.batch_shape:
+            self.batch_pixels *= int(b)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.smoe_shared_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _cparams(self, p):
+        shapes = param_shapes(1, self.cfg.kernels, self.cfg.dim, self.cfg.channels)
+        s = _lib.SmoeParams()
+        for name in PARAM_NAMES:
+            t = p[name]
+            if tuple(t.shape) != shapes[name][1:] or t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"parameter {name}: expected contiguous float32 {shapes[name][1:]} on {self.device}")
+            setattr(s, name, t.data_ptr())
+        return s
+
+    def new_lists(self, nb: Optional[int] = None) -> torch.Tensor:
+        """All kernels listed in every batch (smoe.py:315)."""
+        nb = self.num_batches if nb is None else nb
+        K, KW = self.cfg.kernels, self.list_words
+        words = torch.full((nb, KW), -1, dtype=torch.int32, device=self.device)
+        if K % 32:
+            words[:, KW - 1] = (1 << (K % 32)) - 1
+        return words
+
+    def new_adam_state(self, params):
+        return AdamState(params, self.cfg.beta1, self.cfg.beta2)
+
+    def _check_target(self, target, nb):
+        want = (nb, self.cfg.channels, self.batch_pixels)
+        if tuple(target.shape) != want or target.dtype != torch.float32 or not target.is_contiguous():
+            raise ValueError(f"target must be contiguous float32 {want}")
+
+    def forward(self, target, params, lists, first_batch=0, want_recon=True, want_argmax=False, update_lists=True):
+        nb = lists.shape[0]
+        self._check_target(target, nb)
+        dev = self.device
+        out = {"loss": torch.empty((nb,), dtype=torch.float32, device=dev),
+               "sse": torch.empty((nb,), dtype=torch.float32, device=dev),
+               "recon": torch.empty_like(target) if want_recon else None,
+               "argmax": torch.empty((nb, self.batch_pixels), dtype=torch.int32, device=dev) if want_argmax else None}
+        cp = self._cparams(params)
+        _lib.check(self.lib.smoe_shared_forward(self._h, first_batch, nb, _ptr(target), C.byref(cp), _ptr(out["recon"]),
+                                                _ptr(out["argmax"]), _ptr(out["loss"]), _ptr(out["sse"]), _ptr(lists),
+                                                int(update_lists), self._stream()))
+        return out
+
+    def accumulate(self, target, params, lists, first_batch=0, loss_out=None, sse_out=None):
+        nb = lists.shape[0]
+        self._check_target(target, nb)
+        cp = self._cparams(params)
+        _lib.check(self.lib.smoe_shared_accumulate(self._h, first_batch, nb, _ptr(target), C.byref(cp), _ptr(loss_out),
+                                                   _ptr(sse_out), _ptr(lists), self._stream()))
+
+    def apply(self, params, state: AdamState):
+        state.c.m = self._cparams(state.m)
+        state.c.v = self._cparams(state.v)
+        cp = self._cparams(params)
+        _lib.check(self.lib.smoe_shared_apply(self._h, C.byref(cp), C.byref(state.c), self._stream()))
+
+    def fit(self, target, params, state: AdamState, lists, n_iters, loss_out=None, sse_out=None):
+        self._check_target(target, self.num_batches)
+        state.c.m = self._cparams(state.m)
+        state.c.v = self._cparams(state.v)
+        cp = self._cparams(params)
+        _lib.check(self.lib.smoe_shared_fit(self._h, _ptr(target), C.byref(cp), C.byref(state.c), int(n_iters),
+                                            _ptr(loss_out), _ptr(sse_out), _ptr(lists), self._stream()))
+
+    def update_kernel_list(self, params, lists, first_batch=0):
+        cp = self._cparams(params)
+        _lib.check(self.lib.smoe_shared_update_kernel_list(self._h, first_batch, lists.shape[0], C.byref(cp), _ptr(lists),
+                                                           self._stream()))
+
+    def grad_buffer(self) -> torch.Tensor:
+        """The gradient accumulation buffer as a float64 device tensor view (for the all-reduce
+        between accumulate() and apply() when batches are sharded over ranks)."""
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.smoe_shared_grad_buffer(self._h, C.byref(ptr), C.byref(cnt)))
+        n = int(cnt.value)
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr.value), False), "version": 2}
+        return torch.as_tensor(_Arr(), device=self.device)
+

@@ -1,0 +1,194 @@
+"""GPU parity of the shared-kernel image mode (smoe_shared_*) against the CPU
+restatement (oracle.shared_pass / shared_fit / shared_readmit): one global kernel set, per-batch
+kernel lists, gradients accumulated over the batches of a pass, one Adam step per pass."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import smoe_oracle as o
+from steered_mixture_of_experts_amd import blocks as blk
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # image shape, batch shape, C, kernels_per_dim, yuv
+    ((64, 64), (16, 16), 1, [4, 4], False),
+    ((64, 96), (32, 32), 3, [3, 5], True),
+    ((96, 64), (32, 64), 1, [6, 4], False),        # 2048-pixel batches: 8 pixels per lane
+    ((32, 32, 8), (16, 16, 4), 3, [2, 2, 2], True),
+    ((48, 40), (16, 8), 1, [12, 12], False),       # 144 kernels: several LDS chunks of the list
+]
+
+
+def _image(shape, C, seed):
+    d = len(shape)
+    bs = (16, 16) if d == 2 else (16, 16, 4)
+    g = [-(-s // b) for s, b in zip(shape, bs)]
+    b = blk.synthetic_blocks(int(np.prod(g)), bs, C, seed)
+    full = blk.blocks_to_image(b, tuple(gi * bi for gi, bi in zip(g, bs)), bs)
+    return np.ascontiguousarray(full[tuple(slice(0, s) for s in shape)])
+
+
+def _setup(shape, bshape, C, kpd, yuv, seed=5, perturb=True, **kw):
+    img = _image(shape, C, seed)
+    p = o.shared_init_params(img, kpd)
+    K = p["pis"].shape[1]
+    rng = np.random.default_rng(seed)
+    if perturb:
+        p["A_corr"] = (rng.normal(size=p["A_corr"].shape) * 1.0).astype(np.float32)
+        p["gamma_e"] = (rng.normal(size=p["gamma_e"].shape) * 0.1).astype(np.float32)
+        p["musX"] = (p["musX"] + rng.normal(size=p["musX"].shape) * 0.01).astype(np.float32)
+        p["pis"] = (p["pis"] * rng.uniform(0.5, 1.5, size=p["pis"].shape)).astype(np.float32)
+    cfg = o.OracleConfig(block_shape=bshape, channels=C, kernels=K, use_yuv=yuv, **kw)
+    coords = o.global_batch_coords(shape, bshape)
+    tb, _ = blk.image_to_blocks(img, bshape)
+    NB = tb.shape[0]
+    tgt = tb.reshape(NB, -1, C)
+    return img, p, cfg, coords, tgt, K, NB
+
+
+def _engine(shape, bshape, C, K, yuv, **kw):
+    from steered_mixture_of_experts_amd.engine import SharedConfig, SharedEngine
+    return SharedEngine(SharedConfig(image_shape=shape, batch_shape=bshape, channels=C, kernels=K, use_yuv=yuv, **kw))
+
+
+def _dev(p):
+    return {k: torch.from_numpy(np.ascontiguousarray(v[0])).cuda() for k, v in p.items()}
+
+
+def _bits(mask):
+    NB, K = mask.shape
+    KW = (K + 31) // 32
+    out = np.zeros((NB, KW), np.uint32)
+    for k in range(K):
+        out[:, k >> 5] |= (mask[:, k].astype(np.uint32) << np.uint32(k & 31))
+    return out
+
+
+def _mask(bits, K):
+    return np.stack([(bits[:, k >> 5] >> np.uint32(k & 31)) & 1 for k in range(K)], axis=1).astype(bool)
+
+
+@pytest.mark.parametrize("shape,bshape,C,kpd,yuv", CASES)
+def test_shared_forward_parity(shape, bshape, C, kpd, yuv):
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, pis_l1=0.2, u_l1=0.003)
+    rng = np.random.default_rng(1)
+    lists = rng.uniform(size=(NB, K)) < 0.9
+    p["pis"][0, 1] = 0.0
+    ref = o.shared_pass(p, tgt, coords, lists, cfg, np.float32)
+    ref64 = o.shared_pass(p, tgt, coords, lists, cfg, np.float64)
+    eng = _engine(shape, bshape, C, K, yuv, pis_l1=0.2, u_l1=0.003)
+    assert eng.num_batches == NB
+    dp = _dev(p)
+    dl = torch.from_numpy(_bits(lists).view(np.int32)).cuda()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    out = eng.forward(T, dp, dl, want_recon=True, want_argmax=True)
+    torch.cuda.synchronize()
+    recon = out["recon"].cpu().numpy().transpose(0, 2, 1)
+    frac = (np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie = (frac < 2e-4) | (frac > 1 - 2e-4)
+    d = np.abs(recon - ref["recon"])
+    assert (d[~tie] < 1e-7).all() and (d <= 1.0001 / 255).all()
+    refq = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float32, q_override=recon)
+    assert np.allclose(out["loss"].cpu().numpy(), refq["loss"], rtol=3e-5, atol=1e-9)
+    assert np.allclose(out["sse"].cpu().numpy(), refq["sse"], rtol=3e-5, atol=1e-9)
+    near_tau = (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any(axis=2)
+    new = _mask(dl.cpu().numpy().view(np.uint32), K)
+    assert (new == ref["lists_new"])[~near_tau].all()
+    srt = np.sort(ref64["wt"], axis=1)
+    close_top = (srt[:, -1, :] - srt[:, -2, :]) < 1e-6
+    ok = (out["argmax"].cpu().numpy() == ref["argmax"]) | close_top | near_tau.any(axis=1)[:, None]
+    assert ok.all()
+    eng.close()
+
+
+@pytest.mark.parametrize("shape,bshape,C,kpd,yuv", CASES)
+def test_shared_one_step_gradients_and_adam(shape, bshape, C, kpd, yuv):
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, pis_l1=0.05, u_l1=0.001)
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, yuv, pis_l1=0.05, u_l1=0.001)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True, update_lists=False)
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    f64 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float64, want_grads=True, q_override=recon)
+    g64 = {k: v.sum(axis=0) for k, v in f64["grads"].items()}
+    st = eng.new_adam_state(dp)
+    loss = torch.zeros(NB, device="cuda")
+    eng.accumulate(T, dp, dl, loss_out=loss)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    assert np.allclose(loss.cpu().numpy(), f64["loss"], rtol=3e-5)
+    # gate values on the influence threshold / blends on the clip edge make the gradient discontinuous
+    bad = (np.abs(f64["w"] - 0.5 / 256) < 1e-6).any() or ((np.abs(f64["y"]) < 1e-6) | (np.abs(f64["y"] - 1) < 1e-6)).any()
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g64[name]).max() + 1e-30
+        err = np.abs(st.m[name].cpu().numpy() / 0.1 - g64[name]).max() / scale
+        assert err < (2e-3 if bad else 3e-5), (name, err)
+    assert st.step == 1
+    eng.close()
+
+
+def test_shared_short_fit_and_readmission():
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False, perturb=False)
+    n = 12
+    p32, st32, i32 = o.shared_fit(p, tgt, coords, cfg, n, val_iter=6, dtype=np.float32)
+    p64, _, i64 = o.shared_fit(p, tgt, coords, cfg, n, val_iter=6, dtype=np.float64)
+    eng = _engine(shape, bshape, C, K, False)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    st = eng.new_adam_state(dp)
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    hist = []
+    f0 = eng.forward(T, dp, dl, want_recon=False)
+    hist.append(float(f0["loss"].mean()))
+    for _ in range(2):
+        eng.fit(T, dp, st, dl, 6)
+        eng.update_kernel_list(dp, dl)
+        fv = eng.forward(T, dp, dl, want_recon=False)
+        hist.append(float(fv["loss"].mean()))
+    torch.cuda.synchronize()
+    assert abs(hist[0] - i32["hist"]["loss"][0]) < 1e-7
+    assert np.allclose(hist, i32["hist"]["loss"], rtol=0.05)
+    assert hist[-1] < hist[0]
+    got = {k: v.cpu().numpy()[None] for k, v in dp.items()}
+    for name in ("nu_e", "musX", "pis", "gamma_e"):
+        dev = np.median(np.abs(got[name] - p32[name]))
+        floor = np.median(np.abs(p32[name] - p64[name]))
+        assert dev <= 3 * floor + 1e-6, (name, dev, floor)
+    lists = _mask(dl.cpu().numpy().view(np.uint32), K)
+    assert (lists == i32["lists"]).mean() > 0.97
+    # readmission alone, from empty lists
+    empty = torch.zeros_like(dl)
+    eng.update_kernel_list(dp, empty)
+    want = o.shared_readmit({k: v for k, v in got.items()}, np.zeros((NB, K), bool), coords, cfg, np.float32)
+    assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want)
+    eng.close()
+
+
+def test_shared_batch_sharding_matches_single_launch():
+    """Batches processed as two ranges (what two ranks would do) + summed gradient buffers give the
+    same accumulated gradient as one launch over all batches."""
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False)
+    eng = _engine(shape, bshape, C, K, False)
+    dp = _dev(p)
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    l1 = eng.new_lists()
+    eng.accumulate(T, dp, l1)
+    full = eng.grad_buffer().clone()
+    eng.grad_buffer().zero_()
+    l2 = eng.new_lists()
+    h = NB // 2 + 1
+    eng.accumulate(T[:h].contiguous(), dp, l2[:h], first_batch=0)
+    a = eng.grad_buffer().clone()
+    eng.grad_buffer().zero_()
+    eng.accumulate(T[h:].contiguous(), dp, l2[h:], first_batch=h)
+    b = eng.grad_buffer().clone()
+    torch.cuda.synchronize()
+    assert float((a + b - full).abs().max()) <= 1e-10 * float(full.abs().max())      # fp64 atomics, different order
+    assert torch.equal(l1, l2)
+    eng.grad_buffer().zero_()
+    eng.close()
