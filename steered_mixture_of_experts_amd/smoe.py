@@ -505,3 +505,269 @@ class Smoe:
         self.iter = st["iter"]
         self.losses, self.mses, self.num_pis = st["losses"], st["mses"], st["num_pis"]
         self.valid = False
+
+
+# =====================================================================================================
+# shared-kernel image mode: the reference's whole-image fit
+# =====================================================================================================
+def _default_shared_factory(cfg, device):
+    from .engine import SharedEngine
+    return SharedEngine(cfg, device)
+
+
+class SharedSmoe:
+    """``Smoe`` with ONE global kernel set, as the reference fits whole images
+    (``Smoe(image, kernels_per_dim=[12, 12], batch_size=[32, 32])``): ``kernels_per_dim`` is the
+    global kernel grid, ``batch_size`` the pixel batch of a pass (smoe.py:231-247), every batch keeps
+    its own kernel list (smoe.py:315,1763-1766,2287-2365), the gradients of all batches are
+    accumulated and one Adam step follows (smoe.py:1148-1150,1788).  ``get_params()`` returns the
+    reference's layout exactly (leading axis = kernels).  Multi-GPU: the BATCHES are sharded over
+    ranks and the accumulated gradient buffer is all-reduced (RCCL) before the Adam step.
+    ``overlap_of_batches`` must be 0."""
+
+    def __init__(self, image, kernels_per_dim=None, train_pis=True, init_params=None, start_batches=1,
+                 batch_size=None, train_gammas=True, train_musx=True, use_determinant=False, normalize_pis=True,
+                 use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
+                 engine_factory=None, **unsupported):
+        for name, val in unsupported.items():
+            if val:
+                raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
+        if overlap_of_batches:
+            raise NotImplementedError("overlapping batches are not built (SURVEY 8(f-1) halo)")
+        assert kernels_per_dim is not None or init_params is not None, \
+            "You need to specify the kernel grid size or give initial parameters."
+        image = np.asarray(image, dtype=np.float32)
+        self.image = image
+        d = self.dim_domain = image.ndim - 1
+        self.num_pixel = int(np.prod(image.shape[:d]))
+        self.precision, self.margin = precision, margin
+        self.use_yuv = bool(use_yuv) and image.shape[-1] == 3
+        self.use_determinant = use_determinant
+        self.train_pis, self.train_gammas, self.train_musx = train_pis, train_gammas, train_musx
+        self.quantization_mode, self.quantize_pis = 0, False
+        self.bit_depths = self.lower_bounds = self.upper_bounds = None
+        self.only_y_gamma = self.ssim_opt = self.use_diff_center = self.radial_as = False
+        self.overlap = 0
+        if batch_size is None or batch_size[0] is None:
+            bs = tuple(image.shape[:d])
+        elif len(batch_size) == d:
+            bs = tuple(int(b) for b in batch_size)
+        elif len(batch_size) == 1:
+            bs = tuple(int(batch_size[0]) for _ in range(d))
+        else:
+            raise ValueError("Required BatchSize doesn't fit to input dimension")
+        for ii in range(d):                                               # smoe.py:239-241
+            if image.shape[ii] % bs[ii] > 0:
+                raise ValueError("Required BatchSize is not compatible to input dimensions")
+        self.batch_size_valued = self.batch_size = bs
+        self.Nb = int(np.prod(bs))
+        blocks_all, _ = blk.image_to_blocks(image, bs)
+        self.num_batches = self.start_batches = blocks_all.shape[0]
+        self.rank, self.world_size = sdist.world()
+        self.lo, self.hi = sdist.shard_range(self.num_batches, self.rank, self.world_size)
+        if init_params:
+            p0 = {k: np.ascontiguousarray(init_params[k], dtype=np.float32) for k in PARAM_NAMES}
+            self.musX_init = p0["musX"]
+        else:
+            kpd = list(kernels_per_dim)
+            if len(kpd) == 1:
+                kpd = kpd * d
+            p0 = {k: v[0] for k, v in blk.init_block_params(image[None], kpd, normalize_pis).items()}
+            self.musX_init = blk.gen_domain_grid(kpd, d)
+        self.kernels = self.start_pis = self.kernel_count = p0["pis"].shape[0]
+        self._factory = engine_factory or _default_shared_factory
+        self._device = device
+        self._engine, self._engine_key = None, None
+        self.optimizer1 = self.optimizer2 = self.optimizer3 = None
+        self.grad_clip_value_abs = None
+        self._make_engine(0.0, 0.0)
+        dev = self._engine.device
+        self._target = torch.from_numpy(blk.to_planar(blocks_all[self.lo:self.hi])).to(dev)
+        self._params = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in p0.items()}
+        self._best = {k: v.clone() for k, v in self._params.items()}
+        self._state = self._engine.new_adam_state(self._params)
+        self._lists = self._engine.new_lists(self.hi - self.lo)           # smoe.py:315
+        self.losses, self.mses, self.num_pis, self.num_svs = [], [], [], []
+        self.losses_history, self.mses_history = [], []
+        self.best_loss, self.best_mse = None, []
+        self.iter = iter_offset
+        self.valid = False
+        self.reconstruction_image = self.weight_matrix_argmax = None
+
+    def _make_engine(self, pis_l1, u_l1):
+        from .engine import SharedConfig
+        o1, o2, o3 = self.optimizer1, self.optimizer2, self.optimizer3
+        cfg = SharedConfig(
+            image_shape=tuple(self.image.shape[:self.dim_domain]), batch_shape=self.batch_size_valued,
+            channels=self.image.shape[-1], kernels=self.kernels, precision=self.precision, margin=self.margin,
+            use_determinant=bool(self.use_determinant), use_yuv=bool(self.use_yuv), train_pis=bool(self.train_pis),
+            train_gammas=bool(self.train_gammas), train_musx=bool(self.train_musx),
+            lr_expert=o1._lr if o1 else 0.0, lr_pis=o2._lr if o2 else 0.0, lr_steer=o3._lr if o3 else 0.0,
+            beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999, adam_eps=o1._epsilon if o1 else 1e-8,
+            grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
+            start_pis=self.kernels)
+        key = repr(sorted(cfg.__dict__.items()))
+        if key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = self._factory(cfg, self._device)
+            self._engine_key = key
+
+    @property
+    def kernel_list_per_batch(self):
+        bits = self._lists.cpu().numpy().view(np.uint32)
+        K = self.kernels
+        return [np.array([(row[k >> 5] >> (k & 31)) & 1 for k in range(K)], dtype=bool) for row in bits]
+
+    def set_optimizer(self, optimizer1, optimizer2=None, optimizer3=None, optimizer4=None, optimizer5=None,
+                      grad_clip_value_abs=None):
+        self.optimizer1 = optimizer1
+        self.optimizer2 = optimizer1 if optimizer2 is None else optimizer2
+        self.optimizer3 = optimizer1 if optimizer3 is None else optimizer3
+        self.grad_clip_value_abs = grad_clip_value_abs
+        self._make_engine(0.0, 0.0)
+        self._state = self._engine.new_adam_state(self._params)
+
+    def _global(self, loss, sse):
+        s = torch.stack([loss.double().sum(), sse.double().sum()])
+        sdist.allreduce_sum_(s)
+        s = s.cpu().numpy()
+        loss_val = float(s[0]) * self.Nb / self.num_pixel                              # smoe.py:1758
+        mse_val = float(s[1]) / (self.num_pixel * self.image.shape[-1]) * (2 ** self.precision) ** 2
+        return loss_val, mse_val, int((self._params["pis"] > 0).sum().item())
+
+    def run_batched(self, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, train=True, update_reconstruction=False, **kw):
+        for name, val in kw.items():
+            if val not in (False, None, 100):
+                raise NotImplementedError(f"run_batched({name}=...) is outside the hot path")
+        self.valid = False
+        self._make_engine(pis_l1, u_l1)
+        eng, nb = self._engine, self.hi - self.lo
+        dev = eng.device
+        if train:
+            assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
+            loss = torch.zeros((nb,), dtype=torch.float32, device=dev)
+            sse = torch.zeros((nb,), dtype=torch.float32, device=dev)
+            eng.accumulate(self._target, self._params, self._lists, first_batch=self.lo, loss_out=loss, sse_out=sse)
+            if self.world_size > 1:
+                sdist.allreduce_sum_(eng.grad_buffer())                    # the gradient exchange of the pass
+            eng.apply(self._params, self._state)
+        else:
+            out = eng.forward(self._target, self._params, self._lists, first_batch=self.lo,
+                              want_recon=update_reconstruction, want_argmax=update_reconstruction)
+            loss, sse = out["loss"], out["sse"]
+            if update_reconstruction:
+                bs, d = self.batch_size_valued, self.dim_domain
+                rec = sdist.allgather_blocks(blk.from_planar(out["recon"].cpu().numpy(), bs), self.num_batches)
+                self.reconstruction_image = blk.blocks_to_image(rec, self.image.shape[:d], bs)
+                am = out["argmax"].cpu().numpy().astype(np.int64).reshape((nb,) + bs)
+                am = sdist.allgather_blocks(am, self.num_batches)
+                self.weight_matrix_argmax = blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
+                self.valid = True
+        loss_val, mse_val, num_pi = self._global(loss, sse)
+        return loss_val, mse_val, num_pi, 0
+
+    def train(self, num_iter, val_iter=100, ukl_iter=None, optimizer1=None, optimizer2=None, optimizer3=None,
+              grad_clip_value_abs=None, pis_l1=0, u_l1=0, callbacks=(), **kw):
+        if ukl_iter is None:
+            ukl_iter = val_iter
+        if optimizer1:
+            self.set_optimizer(optimizer1, optimizer2, optimizer3, grad_clip_value_abs=grad_clip_value_abs)
+        assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
+        self.best_loss, self.best_mse, num_pi, num_sv = self.run_batched(
+            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+        self.losses.append((self.iter, self.best_loss))
+        self.mses.append((self.iter, self.best_mse))
+        self.num_pis.append((self.iter, num_pi))
+        self.num_svs.append((self.iter, num_sv))
+        for cb in callbacks:
+            cb(self)
+        loss_val, mse_val = self.best_loss, self.best_mse
+        eng = self._engine
+        single = self.world_size == 1
+        i = 0
+        while i < num_iter:
+            nxt = min(num_iter, (i // val_iter + 1) * val_iter, (i // ukl_iter + 1) * ukl_iter)
+            n = nxt - i
+            if single:                                                       # n x (accumulate; apply) in one call
+                eng.fit(self._target, self._params, self._state, self._lists, n)
+            else:
+                for _ in range(n):
+                    eng.accumulate(self._target, self._params, self._lists, first_batch=self.lo)
+                    sdist.allreduce_sum_(eng.grad_buffer())
+                    eng.apply(self._params, self._state)
+            i = nxt
+            self.iter += n
+            self.valid = False
+            validate = i % val_iter == 0
+            if i % ukl_iter == 0:                                            # smoe.py:1531-1536
+                eng.update_kernel_list(self._params, self._lists, first_batch=self.lo)
+                if not validate:
+                    loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
+            if validate:
+                loss_val, mse_val, num_pi, num_sv = self.run_batched(
+                    pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+                if np.isnan(loss_val) or loss_val + 1 > (self.losses[0][1] + 100) * 10:   # smoe.py:1565-1570
+                    print("stop")
+                    break
+                if not self.best_loss or loss_val < self.best_loss:           # smoe.py:1574-1576
+                    self.best_loss = loss_val
+                    for k in PARAM_NAMES:
+                        self._best[k].copy_(self._params[k])
+                self.losses.append((self.iter, loss_val))
+                if not self.best_mse or mse_val < self.best_mse:
+                    self.best_mse = mse_val
+                self.mses.append((self.iter, mse_val))
+                self.num_pis.append((self.iter, num_pi))
+                self.num_svs.append((self.iter, num_sv))
+                for cb in callbacks:
+                    cb(self)
+        self.losses_history.append(self.losses)
+        self.mses_history.append(self.mses)
+        if self.rank == 0:
+            print("end loss/mse: ", loss_val, "/", mse_val, "@iter: ", i)
+            print("best loss/mse: ", self.best_loss, "/", self.best_mse)
+
+    def get_params(self):
+        return {k: v.cpu().numpy().copy() for k, v in self._params.items()}
+
+    def get_best_params(self):
+        return {k: v.cpu().numpy().copy() for k, v in self._best.items()}
+
+    def get_reconstruction(self):
+        if not self.valid:
+            self.run_batched(train=False, update_reconstruction=True)
+        return self.reconstruction_image
+
+    def get_weight_matrix_argmax(self):
+        if not self.valid:
+            self.run_batched(train=False, update_reconstruction=True)
+        return self.weight_matrix_argmax
+
+    def get_psnr(self):
+        rec = self.get_reconstruction()
+        return float(-10.0 * np.log10(np.mean((rec.astype(np.float64) - self.image.astype(np.float64)) ** 2)))
+
+    def get_losses(self):
+        return self.losses
+
+    def get_mses(self):
+        return self.mses
+
+    def get_num_pis(self):
+        return self.num_pis
+
+    def get_num_svs(self):
+        return self.num_svs
+
+    def get_best_loss(self):
+        return self.best_loss
+
+    def get_best_mse(self):
+        return self.best_mse
+
+    def get_iter(self):
+        return self.iter
+
+    def get_original_image(self):
+        return np.squeeze(self.image)

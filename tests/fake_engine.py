@@ -117,3 +117,113 @@ class OracleEngine:
 
     def fit_variant(self, B):
         return "oracle"
+
+
+class OracleSharedEngine:
+    """Test double of ``SharedEngine`` on the numpy oracle (shared-kernel mode), torch CPU tensors."""
+
+    def __init__(self, cfg, device=None):
+        self.cfg = cfg
+        self.device = torch.device("cpu")
+        self.ocfg = o.OracleConfig(
+            block_shape=tuple(cfg.batch_shape), channels=cfg.channels, kernels=cfg.kernels, precision=cfg.precision,
+            margin=cfg.margin, use_determinant=cfg.use_determinant, use_yuv=cfg.use_yuv, train_pis=cfg.train_pis,
+            train_gammas=cfg.train_gammas, train_musx=cfg.train_musx, lr_expert=cfg.lr_expert, lr_pis=cfg.lr_pis,
+            lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2, adam_eps=cfg.adam_eps,
+            grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1, start_pis=cfg.start_pis or cfg.kernels)
+        self.coords = o.global_batch_coords(cfg.image_shape, cfg.batch_shape)
+        self.num_batches = self.coords.shape[0]
+        self.list_words = (cfg.kernels + 31) // 32
+        self.batch_pixels = self.coords.shape[1]
+        self._sizes = None
+        self._buf = None
+
+    def close(self):
+        pass
+
+    def new_adam_state(self, params):
+        return _State(params, self.cfg.beta1, self.cfg.beta2)
+
+    def new_lists(self, nb=None):
+        nb = self.num_batches if nb is None else nb
+        K, KW = self.cfg.kernels, self.list_words
+        w = torch.full((nb, KW), -1, dtype=torch.int32)
+        if K % 32:
+            w[:, KW - 1] = (1 << (K % 32)) - 1
+        return w
+
+    def _mask(self, lists):
+        bits = lists.numpy().view(np.uint32)
+        K = self.cfg.kernels
+        return np.stack([(bits[:, k >> 5] >> np.uint32(k & 31)) & 1 for k in range(K)], axis=1).astype(bool)
+
+    def _setbits(self, lists, mask):
+        bits = lists.numpy().view(np.uint32)
+        bits[:] = 0
+        for k in range(self.cfg.kernels):
+            bits[:, k >> 5] |= (mask[:, k].astype(np.uint32) << np.uint32(k & 31))
+
+    def _p(self, params):
+        return {k: params[k].numpy()[None] for k in NAMES}
+
+    def forward(self, target, params, lists, first_batch=0, want_recon=True, want_argmax=False, update_lists=True):
+        nb = lists.shape[0]
+        tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
+        f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg)
+        if update_lists:
+            self._setbits(lists, f["lists_new"])
+        return {"loss": torch.from_numpy(f["loss"].astype(np.float32)), "sse": torch.from_numpy(f["sse"].astype(np.float32)),
+                "recon": torch.from_numpy(np.ascontiguousarray(f["recon"].transpose(0, 2, 1))) if want_recon else None,
+                "argmax": torch.from_numpy(f["argmax"].astype(np.int32)) if want_argmax else None}
+
+    def grad_buffer(self):
+        if self._buf is None:
+            n = sum(int(np.prod(s)) for s in self._shapes().values())
+            self._buf = torch.zeros(n, dtype=torch.float64)
+        return self._buf
+
+    def _shapes(self):
+        K, d, C = self.cfg.kernels, len(self.cfg.image_shape), self.cfg.channels
+        return {"pis": (K,), "musX": (K, d), "A_diagonal": (K, d, d), "A_corr": (K, d, d), "gamma_e": (K, d, C), "nu_e": (K, C)}
+
+    def accumulate(self, target, params, lists, first_batch=0, loss_out=None, sse_out=None):
+        nb = lists.shape[0]
+        tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
+        f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg,
+                          np.float32, want_grads=True)
+        self._setbits(lists, f["lists_new"])
+        buf = self.grad_buffer()
+        flat = np.concatenate([f["grads"][k][0].astype(np.float64).ravel() for k in NAMES])
+        buf += torch.from_numpy(flat)
+        if loss_out is not None:
+            loss_out.copy_(torch.from_numpy(f["loss"].astype(np.float32)))
+        if sse_out is not None:
+            sse_out.copy_(torch.from_numpy(f["sse"].astype(np.float32)))
+
+    def apply(self, params, state):
+        buf = self.grad_buffer().numpy()
+        grads, off = {}, 0
+        for k, shp in self._shapes().items():
+            n = int(np.prod(shp))
+            grads[k] = buf[off:off + n].reshape((1,) + shp).astype(np.float32)
+            off += n
+        st = {"m": {k: state.m[k].numpy()[None] for k in NAMES}, "v": {k: state.v[k].numpy()[None] for k in NAMES},
+              "t": state._step, "b1p": np.float32(state.c.beta1_power), "b2p": np.float32(state.c.beta2_power)}
+        newp = o.adam_step(self._p(params), grads, st, self.ocfg, np.float32)
+        for k in NAMES:
+            params[k].copy_(torch.from_numpy(np.ascontiguousarray(newp[k][0])))
+            state.m[k].copy_(torch.from_numpy(np.ascontiguousarray(st["m"][k][0])))
+            state.v[k].copy_(torch.from_numpy(np.ascontiguousarray(st["v"][k][0])))
+        state._step += 1
+        state.c.beta1_power, state.c.beta2_power, state.c.step = float(st["b1p"]), float(st["b2p"]), state._step
+        self._buf.zero_()
+
+    def fit(self, target, params, state, lists, n_iters, loss_out=None, sse_out=None):
+        for _ in range(n_iters):
+            self.accumulate(target, params, lists, 0, loss_out, sse_out)
+            self.apply(params, state)
+
+    def update_kernel_list(self, params, lists, first_batch=0):
+        nb = lists.shape[0]
+        new = o.shared_readmit(self._p(params), self._mask(lists), self.coords[first_batch:first_batch + nb], self.ocfg)
+        self._setbits(lists, new)

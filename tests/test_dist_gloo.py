@@ -29,6 +29,14 @@ s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
 s.train(6, val_iter=3)
 out = {"params": s.get_params(), "losses": s.get_losses(), "mses": s.get_mses(), "num_pis": s.get_num_pis(),
        "recon": s.get_reconstruction(), "span": (s.lo, s.hi), "argmax": s.get_weight_matrix_argmax()}
+# shared-kernel mode: batches sharded, accumulated gradient buffer all-reduced before the Adam step
+from fake_engine import OracleSharedEngine
+from steered_mixture_of_experts_amd.smoe import SharedSmoe
+g = SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True, engine_factory=OracleSharedEngine)
+g.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+g.train(4, val_iter=2)
+out["shared"] = {"params": g.get_params(), "losses": g.get_losses(), "recon": g.get_reconstruction(),
+                 "lists": np.array(g.kernel_list_per_batch), "span": (g.lo, g.hi)}
 if ws == 1 or dist.get_rank() == 0:
     pickle.dump(out, open(sys.argv[2], "wb"))
 if ws > 1:
@@ -63,3 +71,9 @@ def test_two_ranks_equal_one(tmp_path):
     assert np.allclose([v for _, v in a["losses"]], [v for _, v in b["losses"]], rtol=1e-12)
     assert np.allclose([v for _, v in a["mses"]], [v for _, v in b["mses"]], rtol=1e-12)
     assert a["num_pis"] == b["num_pis"]
+    sa, sb = a["shared"], b["shared"]
+    assert sa["span"] == (0, 15) and sb["span"] == (0, 8)
+    for k in sa["params"]:                       # the all-reduced gradient sum differs only in summation order
+        assert np.allclose(sa["params"][k], sb["params"][k], rtol=1e-5, atol=1e-6), k
+    assert np.allclose([v for _, v in sa["losses"]], [v for _, v in sb["losses"]], rtol=1e-5)
+    assert (np.abs(sa["recon"] - sb["recon"]) < 1.5 / 255).mean() > 0.999

@@ -176,3 +176,32 @@ def test_smoe_reconstruction_entry_point(tmp_path):
         assert recon_q.shape == recon.shape and np.abs(recon_q - recon).mean() < 0.02
     finally:
         smod._default_engine_factory = orig_factory
+
+
+def test_shared_kernel_facade_matches_the_numpy_restatement():
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(64, 48)
+    s = SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[16, 16], use_determinant=True,
+                   engine_factory=OracleSharedEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    assert s.num_batches == 12 and s.kernels == 12
+    s.train(8, val_iter=4)
+    p0 = o.shared_init_params(img, [4, 3])
+    coords = o.global_batch_coords((64, 48), (16, 16))
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=12)
+    pn, st, info = o.shared_fit(p0, tb.reshape(12, -1, 1), coords, cfg, 8, val_iter=4, dtype=np.float32)
+    got = s.get_params()
+    assert got["musX"].shape == (12, 2) and got["A_diagonal"].shape == (12, 2, 2)       # the reference's layout
+    for k in got:
+        assert np.allclose(got[k], pn[k][0], rtol=1e-5, atol=1e-6), k
+    assert [i for i, _ in s.get_losses()] == [0, 4, 8]
+    assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-6)
+    assert np.allclose([v for _, v in s.get_mses()], info["hist"]["mse"], rtol=1e-6)
+    assert s.get_reconstruction().shape == img.shape and s.get_weight_matrix_argmax().max() < 12
+    assert np.array_equal(np.array(s.kernel_list_per_batch), info["lists"])
+    with pytest.raises(ValueError):
+        SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[10, 16], engine_factory=OracleSharedEngine)
+    with pytest.raises(NotImplementedError):
+        SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[16, 16], overlap_of_batches=2, engine_factory=OracleSharedEngine)

@@ -192,3 +192,26 @@ def test_shared_batch_sharding_matches_single_launch():
     assert torch.equal(l1, l2)
     eng.grad_buffer().zero_()
     eng.close()
+
+
+def test_shared_facade_on_gpu_matches_the_oracle_backed_facade():
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import Adam, SharedSmoe
+    img = _image((64, 96), 1, 77)
+
+    def run(factory):
+        s = SharedSmoe(img, kernels_per_dim=[4, 6], batch_size=[16, 32], use_determinant=True, engine_factory=factory)
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+        s.train(10, val_iter=5)
+        return s
+
+    g, c = run(None), run(OracleSharedEngine)
+    assert [i for i, _ in g.get_losses()] == [0, 5, 10]
+    assert abs(g.get_losses()[0][1] - c.get_losses()[0][1]) < 1e-7
+    assert np.allclose([v for _, v in g.get_losses()], [v for _, v in c.get_losses()], rtol=0.03)
+    pg, pc = g.get_params(), c.get_params()
+    for k in ("nu_e", "musX", "pis"):
+        assert np.median(np.abs(pg[k] - pc[k])) < 2e-5, k
+    assert abs(g.get_psnr() - c.get_psnr()) < 0.2
+    assert g.get_losses()[-1][1] < g.get_losses()[0][1]
+    assert g.get_weight_matrix_argmax().shape == (64, 96)
