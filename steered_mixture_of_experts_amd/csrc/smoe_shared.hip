@@ -124,8 +124,12 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         for (int c = 0; c < C; ++c) t[p][c] = a.target[((size_t)b * C + c) * Nb + (pv[p] ? n : 0)];
     }
 
-    // stage chunk [c0, c0+n) of the active list into LDS (derived quantities, smoe.py:732-733,809-819)
+    // stage chunk [c0, c0+n) of the active list into LDS (derived quantities, smoe.py:732-733,809-819);
+    // a list that fits one chunk (the common case after pruning) is staged once for all three sweeps
+    int staged_c0 = -1;
     auto stage = [&](int c0, int n) {
+        if (c0 == staged_c0) return;
+        staged_c0 = c0;
         __syncthreads();
         if (tid < n) {
             const int k = s_list[c0 + tid];

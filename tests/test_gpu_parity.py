@@ -22,6 +22,9 @@ SHAPES = [
     ((32, 32), 3, [2, 4], True),
     ((16, 16, 4), 3, [2, 2, 1], True),
     ((16, 16), 1, [2, 4], False),
+    # odd shapes: the generic kernels (XL=false: G is not a multiple of the last axis) and ragged pixel counts
+    ((7, 5), 1, [2, 2], False),
+    ((12, 10, 3), 3, [2, 2, 1], True),
 ]
 
 
