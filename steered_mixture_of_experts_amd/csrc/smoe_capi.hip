@@ -258,10 +258,16 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
     a.reg_u = c.u_l1;
     a.kc = h->kc;
-    // lanes walk the block with stride G: when G is a multiple of the last axis, a lane's last
-    // coordinate never changes and the kernel hoists it (fit_kernel<..., XL = true>)
-    const bool xl = (v->G % c.block_shape[c.dim - 1]) == 0;
-    HIP_TRY(v->fit(a, xl, (hipStream_t)stream), "smoe_fit launch");
+    // lanes walk the block with stride G: when G is a multiple of the last axis (of the last two
+    // axes), a lane's last (two) coordinate(s) never change and the kernel hoists them
+    // (fit_kernel<..., HL>)
+    int hoist = 0;
+    const int last = c.block_shape[c.dim - 1];
+    if (v->G % last == 0) {
+        hoist = 1;
+        if (c.dim == 3 && v->G % (last * c.block_shape[c.dim - 2]) == 0) hoist = 2;
+    }
+    HIP_TRY(v->fit(a, hoist, (hipStream_t)stream), "smoe_fit launch");
     // TF multiplies the beta powers after every apply (fp32 running product)
     for (int i = 0; i < n_iters; ++i) {
         s->beta1_power *= c.beta1;

@@ -85,7 +85,7 @@ struct ReduceArgs {
 struct Variant {
     int D, C, K, G, W;
     const char* name;
-    hipError_t (*fit)(const FitArgs&, bool x_last_const, hipStream_t);
+    hipError_t (*fit)(const FitArgs&, int hoist_level, hipStream_t);
     hipError_t (*fwd)(const FwdArgs&, hipStream_t);
     size_t (*lds_bytes)(int N, bool has_lw);
     int (*fit_waves_per_cu)(int N, bool has_lw);

@@ -117,9 +117,9 @@ struct BlockRegs {
     float As[K][Lt::TRI];     // A' = SQ * A (lower triangle)
     float cz[K][D];           // c = A'^T mu, so z' = A'^T x - c
     float coef[K];            // pi * prod diag(A) / sqrt((2pi)^d), 0 when the kernel is inactive
-    // XL specialisation (the lane's last coordinate x_{D-1} is the same for all its pixels):
-    float hz[K][D];           // x_last * A'[D-1][m] - c[m]      (z' = sum_{l<D-1} x_l A'[l][m] + hz[m])
-    float he[K][C];           // nu + gamma[D-1] * x_last          (e  = he + sum_{l<D-1} gamma[l] x_l)
+    // hoisting (HL = number of trailing coordinates that are the same for all pixels of the lane):
+    float hz[K][D];           // sum_{l>=D-HL} x_l A'[l][m] - c[m]   (z' = sum_{l<D-HL} x_l A'[l][m] + hz[m])
+    float he[K][C];           // nu + sum_{l>=D-HL} gamma[l] x_l      (e  = he + sum_{l<D-HL} gamma[l] x_l)
 
     __device__ __forceinline__ float pi(int k) const { return P[k * Lt::PK + Lt::O_PI]; }
     __device__ __forceinline__ float mu(int k, int l) const { return P[k * Lt::PK + Lt::O_MU + l]; }
@@ -186,15 +186,25 @@ __device__ __forceinline__ void uniformize(BlockRegs<D, C, K>& R) {
     }
 }
 
-template <int D, int C, int K>
-__device__ __forceinline__ void hoist_last(BlockRegs<D, C, K>& R, float xl) {
-    using Lt = Layout<D, C, K>;
+template <int D, int C, int K, int HL>
+__device__ __forceinline__ void hoist_const(BlockRegs<D, C, K>& R, const float (&xc)[D]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
 #pragma unroll
-        for (int m = 0; m < D; ++m) R.hz[k][m] = fmaf(xl, R.As[k][tri_index(D - 1, m)], -R.cz[k][m]);
+        for (int m = 0; m < D; ++m) {
+            float h = -R.cz[k][m];
 #pragma unroll
-        for (int c = 0; c < C; ++c) R.he[k][c] = fmaf(R.ga(k, D - 1, c), xl, R.nu(k, c));
+            for (int l = D - 1; l >= D - HL; --l)
+                if (l >= m) h = fmaf(xc[l], R.As[k][tri_index(l, m)], h);
+            R.hz[k][m] = h;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float h = R.nu(k, c);
+#pragma unroll
+            for (int l = D - HL; l < D; ++l) h = fmaf(R.ga(k, l, c), xc[l], h);
+            R.he[k][c] = h;
+        }
     }
 }
 
@@ -211,7 +221,7 @@ struct PixelOut {
 //   acc[A_k,l,m]   += u_k x_l z'_m             (x, not x - mu: corrected in finish_partials)
 //   acc[nu_k,c]    += wt_k G_c     acc[ga_k,l,c] += wt_k G_c x_l
 // The influence slot accumulates sum_n wt_k (> 0 iff some pixel passes the mask, smoe.py:829).
-template <int D, int C, int K, bool TRAIN, bool XL = false>
+template <int D, int C, int K, bool TRAIN, int HL = 0>
 __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                       const float (&x)[D], const float (&t)[C], float lw,
                                       float* __restrict__ acc, PixelOut<D, C, K>& o) {
@@ -224,9 +234,9 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         float maha = 0.0f;
 #pragma unroll
         for (int m = 0; m < D; ++m) {
-            float zz = XL ? R.hz[k][m] : -R.cz[k][m];
+            float zz = (HL > 0) ? R.hz[k][m] : -R.cz[k][m];
 #pragma unroll
-            for (int l = (XL ? D - 2 : D - 1); l >= m; --l) zz = fmaf(x[l], R.As[k][tri_index(l, m)], zz);
+            for (int l = D - 1 - HL; l >= m; --l) zz = fmaf(x[l], R.As[k][tri_index(l, m)], zz);
             z[k][m] = zz;
             maha = (m == 0) ? zz * zz : fmaf(zz, zz, maha);
         }
@@ -244,9 +254,9 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            float ee = XL ? R.he[k][c] : R.nu(k, c);
+            float ee = (HL > 0) ? R.he[k][c] : R.nu(k, c);
 #pragma unroll
-            for (int l = 0; l < (XL ? D - 1 : D); ++l) ee = fmaf(R.ga(k, l, c), x[l], ee);
+            for (int l = 0; l < D - HL; ++l) ee = fmaf(R.ga(k, l, c), x[l], ee);
             e[k][c] = ee;
             y[c] = (k == 0) ? o.wt[k] * ee : fmaf(o.wt[k], ee, y[c]);
         }
@@ -291,7 +301,7 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
             const float uz = u * z[k][m];
             a[Lt::O_MU + m] += uz;
 #pragma unroll
-            for (int l = m; l < (XL ? D - 1 : D); ++l)     // XL: the l = D-1 rows are x_last * sum(uz), done after the loop
+            for (int l = m; l < D - HL; ++l)               // hoisted rows l >= D-HL are x_l * sum(uz), done after the loop
                 a[Lt::O_A + tri_index(l, m)] = fmaf(x[l], uz, a[Lt::O_A + tri_index(l, m)]);
         }
 #pragma unroll
@@ -299,23 +309,26 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
             const float wg = o.wt[k] * Gc[c];
             a[Lt::O_NU + c] += wg;
 #pragma unroll
-            for (int l = 0; l < (XL ? D - 1 : D); ++l)
+            for (int l = 0; l < D - HL; ++l)
                 a[Lt::O_GA + l * C + c] = fmaf(wg, x[l], a[Lt::O_GA + l * C + c]);
         }
     }
 }
 
-// XL: complete the accumulators whose x factor was the lane-constant last coordinate.
-template <int D, int C, int K>
-__device__ __forceinline__ void complete_last(float xl, float* __restrict__ acc) {
+// Hoisting: complete the accumulators whose x factor is one of the lane-constant coordinates.
+template <int D, int C, int K, int HL>
+__device__ __forceinline__ void complete_const(const float (&xc)[D], float* __restrict__ acc) {
     using Lt = Layout<D, C, K>;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float* a = acc + k * Lt::PK;
 #pragma unroll
-        for (int m = 0; m < D; ++m) a[Lt::O_A + tri_index(D - 1, m)] = xl * a[Lt::O_MU + m];
+        for (int l = D - HL; l < D; ++l) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) a[Lt::O_GA + (D - 1) * C + c] = xl * a[Lt::O_NU + c];
+            for (int m = 0; m <= l; ++m) a[Lt::O_A + tri_index(l, m)] = xc[l] * a[Lt::O_MU + m];
+#pragma unroll
+            for (int c = 0; c < C; ++c) a[Lt::O_GA + l * C + c] = xc[l] * a[Lt::O_NU + c];
+        }
     }
 }
 
@@ -460,7 +473,7 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
 // ---------------------------------------------------------------------------
 // fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
 // ---------------------------------------------------------------------------
-template <int D, int C, int K, bool HAS_LW, bool XL>
+template <int D, int C, int K, bool HAS_LW, int HL>
 __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                                  const float* __restrict__ s_coords, const float* __restrict__ s_tgt,
                                                  const float* __restrict__ s_lw, int N, int G, int sub,
@@ -472,20 +485,20 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
         if (n < N) {
             float x[D], t[C];
 #pragma unroll
-            for (int l = 0; l < (XL ? D - 1 : D); ++l) x[l] = s_coords[l * N + n];
-            if (XL) x[D - 1] = 0.0f;
+            for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
 #pragma unroll
             for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
             const float lw = HAS_LW ? s_lw[n] : 1.0f;
             PixelOut<D, C, K> o;
-            pixel<D, C, K, true, XL>(R, kc, x, t, lw, acc, o);
+            pixel<D, C, K, true, HL>(R, kc, x, t, lw, acc, o);
         }
     }
 }
 
-// XL = the host guarantees G % block_shape[D-1] == 0, i.e. pixel n = i*G + sub of a lane always has
-// the same last-axis index: terms in x_{D-1} are hoisted out of the pixel loop.
-template <int D, int C, int K, int G, int WAVES, bool XL>
+// HL = number of trailing axes whose index is the same for every pixel n = i*G + sub of a lane: the host
+// guarantees G % (block_shape[D-1] * ... * block_shape[D-HL]) == 0.  Terms in those coordinates are
+// hoisted out of the pixel loop (HL = 1 for 16x16 blocks with G = 16; HL = 2 for 16x16x4 with G = 64).
+template <int D, int C, int K, int G, int WAVES, int HL>
 __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -572,11 +585,13 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     }
                 }
             }
-            const float xl = s_coords[(D - 1) * N + sub];
-            if (XL) hoist_last<D, C, K>(R, xl);
-            if (has_lw) pixel_loop_train<D, C, K, true, XL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
-            else pixel_loop_train<D, C, K, false, XL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
-            if (XL) complete_last<D, C, K>(xl, acc);
+            float xc[D];
+#pragma unroll
+            for (int l = 0; l < D; ++l) xc[l] = s_coords[l * N + sub];     // pixel i = 0 of the lane
+            if (HL > 0) hoist_const<D, C, K, HL>(R, xc);
+            if (has_lw) pixel_loop_train<D, C, K, true, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+            else pixel_loop_train<D, C, K, false, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+            if (HL > 0) complete_const<D, C, K, HL>(xc, acc);
         }
         {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
@@ -892,10 +907,12 @@ __global__ void reduce_scalars_kernel(ReduceArgs a) {
 // launchers + dispatch table
 // ---------------------------------------------------------------------------
 template <int D, int C, int K, int G, int WAVES>
-hipError_t launch_fit(const FitArgs& a, bool xl, hipStream_t st) {
+hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
-    auto kern = xl ? fit_kernel<D, C, K, G, WAVES, true> : fit_kernel<D, C, K, G, WAVES, false>;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 0>;
+    if (hoist == 1) kern = fit_kernel<D, C, K, G, WAVES, 1>;
+    if (D == 3 && hoist >= 2) kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -922,7 +939,7 @@ template <int D, int C, int K, int G, int WAVES>
 int fit_occupancy(int N, bool has_lw) {
     using T = Tile<D, C, K, G, WAVES>;
     int nb = 0;
-    auto kern = fit_kernel<D, C, K, G, WAVES, true>;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 1>;
     const size_t shm = T::bytes(N, has_lw);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, shm) != hipSuccess) return -1;

@@ -332,3 +332,48 @@ def test_error_paths():
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(3, 1, 100, device="cuda"), eng.new_params(3), torch.zeros(3, dtype=torch.int32, device="cuda"))
     eng.close()
+
+
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
+    """The fit kernel's per-pixel loss-weight path (padding / loss masks, smoe.py:550,932), the l1
+    regularisers (smoe.py:1027,1044) and gradient clipping (smoe.py:1152-1153) against the oracle."""
+    shape, C, kpd, yuv = (16, 16), 3, [2, 2], True
+    B = 19
+    kw = dict(pis_l1=0.3, u_l1=0.002, grad_clip=2e-4)
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 4711, **kw)
+    rng = np.random.default_rng(3)
+    lw = (rng.uniform(size=(B, tgt.shape[1])) < 0.7).astype(np.float32)       # 0/1 mask like the padding mask
+    lw[5] = 0.0                                                                 # a fully masked block
+    active = np.ones((B, K), dtype=bool)
+    active[2, 1] = False
+    eng = _engine(shape, C, K, use_yuv=yuv, **kw)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T, LW = _planar(tgt), torch.from_numpy(lw).cuda()
+    fw = eng.forward(T, dp, act, loss_w=LW, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, lw, np.float32, want_grads=True, q_override=recon)
+    ref64 = o.forward(p, tgt, coords, active, cfg, lw, np.float64, want_grads=True, q_override=recon)
+    st = o.new_adam_state(p)
+    p_ref = o.adam_step({k: v.copy() for k, v in p.items()}, ref["grads"], st, cfg, np.float32)
+    state = eng.new_adam_state(dp)
+    loss = torch.zeros(B, device="cuda")
+    eng.fit(T, dp, state, act, 1, loss_w=LW, loss_out=loss)
+    torch.cuda.synchronize()
+    assert np.allclose(loss.cpu().numpy(), ref["loss"], rtol=3e-5, atol=1e-9)
+    clip = kw["grad_clip"]
+    m = _to_host(state.m)
+    for name in o.PARAM_NAMES:
+        g_clip = np.clip(ref64["grads"][name], -clip, clip)
+        assert np.abs(m[name] / 0.1 - g_clip).max() < 2e-5 * clip + 1e-9, name
+        assert (np.abs(m[name] / 0.1) <= clip * 1.00001).all()
+    assert (np.abs(ref64["grads"]["nu_e"]) > clip).any()                        # the clip actually bites
+    got = _to_host(dp)
+    # block 5 (all weights 0): only the regulariser gradients move pis / A_diagonal
+    assert np.array_equal(got["nu_e"][5], p["nu_e"][5]) and np.array_equal(got["musX"][5], p["musX"][5])
+    assert not np.array_equal(got["pis"][5], p["pis"][5])
+    for name in ("nu_e", "musX", "gamma_e"):
+        assert np.abs(got[name] - p_ref[name]).max() < 2e-5, name
+    eng.close()
