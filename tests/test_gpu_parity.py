@@ -367,7 +367,8 @@ def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     m = _to_host(state.m)
     for name in o.PARAM_NAMES:
         g_clip = np.clip(ref64["grads"][name], -clip, clip)
-        assert np.abs(m[name] / 0.1 - g_clip).max() < 2e-5 * clip + 1e-9, name
+        scale = max(clip, float(np.abs(ref64["grads"][name]).max()))
+        assert np.abs(m[name] / 0.1 - g_clip).max() < 3e-5 * scale + 1e-9, name
         assert (np.abs(m[name] / 0.1) <= clip * 1.00001).all()
     assert (np.abs(ref64["grads"]["nu_e"]) > clip).any()                        # the clip actually bites
     got = _to_host(dp)
