@@ -169,6 +169,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         else kc.cw[c] = (float)(1.0 / ((double)N * C));                                          // smoe.py:937
     }
     kc.n_dis = (float)std::sqrt(std::pow(2.0 * M_PI, (double)D));                                // smoe.py:812
+    kc.inv_n_dis = 1.0f / kc.n_dis;
     kc.use_det = cfg->use_determinant ? 1 : 0;
     kc.train_gammas = cfg->train_gammas ? 1 : 0;
     *out = h;
@@ -444,6 +445,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         else kc.cw[c] = (float)(1.0 / ((double)Nb * C));
     }
     kc.n_dis = (float)std::sqrt(std::pow(2.0 * M_PI, (double)D));
+    kc.inv_n_dis = 1.0f / kc.n_dis;
     kc.use_det = cfg->use_determinant ? 1 : 0;
     kc.train_gammas = cfg->train_gammas ? 1 : 0;
     *out = h;

@@ -20,6 +20,7 @@ struct KernelConsts {
     float nudged_max;   // min(1, (2^p - 1) * scale): upper clamp of clip_by_value + fake quant
     float cw[SMOE_MAX_CHANNELS];  // per-channel loss weight / N   smoe.py:933-937
     float n_dis;        // sqrt((2 pi)^d)                  smoe.py:812
+    float inv_n_dis;    // 1 / n_dis
     int use_det;        // smoe.py:809
     int train_gammas;   // smoe.py:841
 };

@@ -146,7 +146,7 @@ struct BlockRegs {
             float det = 1.0f;
 #pragma unroll
             for (int l = 0; l < D; ++l) det *= A(k, l, l);
-            const float nq = kc.use_det ? det / kc.n_dis : 1.0f;   // n_quo = n_div / n_dis
+            const float nq = kc.use_det ? det * kc.inv_n_dis : 1.0f;   // n_quo = n_div / n_dis (reciprocal from the host)
             coef[k] = act(k) ? nq * pi(k) : 0.0f;
 #pragma unroll
             for (int l = 0; l < D; ++l)
@@ -603,8 +603,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
 
         // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
-        const float one_m_b1p = 1.0f - b1p;
-        const float sq = sqrtf(1.0f - b2p);
+        const float bias = sqrtf(1.0f - b2p) / (1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
         float newp[T::SPL];
         bool bad = false;
 #pragma unroll
@@ -621,7 +620,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 gsum += act ? reg[s] : 0.0f;
             }
             if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
-            const float alpha = lr[s] * sq / one_m_b1p;
+            const float alpha = lr[s] * bias;
             const float m2 = mv + (gsum - mv) * (1.0f - beta1);
             const float v2 = vv + (gsum * gsum - vv) * (1.0f - beta2);
             const float p2 = pv - (m2 * alpha) / (sqrtf(v2) + adam_eps);
