@@ -62,7 +62,9 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
     // lanes per block: few blocks -> spread each block over a whole wavefront (more
     // waves in flight); many blocks -> 16 lanes per block (4 blocks per wavefront, the
     // cross-lane reduction is amortised over 4x more pixels per lane).
-    int want = h->force_g ? h->force_g : ((num_blocks >= 8192) ? 16 : 64);
+    // Large blocks (>= 1024 pixels) always use a whole wavefront per block: 16 lanes would leave 64+
+    // pixels per lane, and with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
+    int want = h->force_g ? h->force_g : ((num_blocks >= 8192 && h->N <= 512) ? 16 : 64);
     const smoe::Variant* fallback = nullptr;
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels) continue;

@@ -386,26 +386,27 @@ struct Tile {
     static constexpr int MV_STRIDE = round_up(2 * Lt::NPAR, 4);   // Adam m,v image of one block
 
     // float offsets inside dynamic LDS
+    // CR = coordinate rows staged in LDS (D, or D - HL when the trailing HL axes are hoisted)
     __host__ __device__ static int off_coords() { return 0; }
-    __host__ __device__ static int off_par(int N) { return round_up(D * N, 4); }
-    __host__ __device__ static int off_mv(int N) { return off_par(N) + NB * Lt::LP_STRIDE; }
-    __host__ __device__ static int off_scratch(int N) { return off_mv(N) + NB * MV_STRIDE; }
-    __host__ __device__ static int off_tgt(int N) { return off_scratch(N) + WAVES * CH * ROW; }
-    __host__ __device__ static int off_lw(int N) { return off_tgt(N) + NB * C * N; }
-    __host__ __device__ static size_t bytes(int N, bool has_lw) {
-        return sizeof(float) * (size_t)(off_lw(N) + (has_lw ? NB * N : 0));
+    __host__ __device__ static int off_par(int N, int CR) { return round_up(CR * N, 4); }
+    __host__ __device__ static int off_mv(int N, int CR) { return off_par(N, CR) + NB * Lt::LP_STRIDE; }
+    __host__ __device__ static int off_scratch(int N, int CR) { return off_mv(N, CR) + NB * MV_STRIDE; }
+    __host__ __device__ static int off_tgt(int N, int CR) { return off_scratch(N, CR) + WAVES * CH * ROW; }
+    __host__ __device__ static int off_lw(int N, int CR) { return off_tgt(N, CR) + NB * C * N; }
+    __host__ __device__ static size_t bytes(int N, bool has_lw, int CR = D) {
+        return sizeof(float) * (size_t)(off_lw(N, CR) + (has_lw ? NB * N : 0));
     }
 };
 
-template <int D, int C, int K, int G, int WAVES>
+template <int D, int C, int K, int G, int WAVES, int CR = D>
 __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, const float* __restrict__ target,
                                              const float* __restrict__ loss_w, int B, int N, int blk0,
                                              float* __restrict__ lds) {
     using T = Tile<D, C, K, G, WAVES>;
     float* s_coords = lds + T::off_coords();
-    float* s_tgt = lds + T::off_tgt(N);
-    float* s_lw = lds + T::off_lw(N);
-    for (int i = threadIdx.x; i < D * N; i += T::THREADS) s_coords[i] = coords[i];
+    float* s_tgt = lds + T::off_tgt(N, CR);
+    float* s_lw = lds + T::off_lw(N, CR);
+    for (int i = threadIdx.x; i < CR * N; i += T::THREADS) s_coords[i] = coords[i];
     const int per = C * N;
     for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) {
         const int lb = i / per;
@@ -515,15 +516,19 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     const bool valid_b = b_raw < B;
     const int b = valid_b ? b_raw : B - 1;
 
+    constexpr int CR = D - HL;                     // only the coordinates read per pixel are staged
     float* s_coords = lds + T::off_coords();
-    float* s_par = lds + T::off_par(N) + lb * Lt::LP_STRIDE;
-    float* s_mv = lds + T::off_mv(N) + lb * T::MV_STRIDE;
-    float* s_scratch = lds + T::off_scratch(N) + wave * (T::CH * T::ROW);
-    const float* s_tgt = lds + T::off_tgt(N) + lb * (C * N);
-    const float* s_lw = lds + T::off_lw(N) + lb * N;
+    float* s_par = lds + T::off_par(N, CR) + lb * Lt::LP_STRIDE;
+    float* s_mv = lds + T::off_mv(N, CR) + lb * T::MV_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N, CR) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N, CR) + lb * (C * N);
+    const float* s_lw = lds + T::off_lw(N, CR) + lb * N;
     const bool has_lw = a.loss_w != nullptr;
 
-    stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    float xc[D];                                   // coordinates of the lane's pixel i = 0 (hoisted axes: all its pixels)
+#pragma unroll
+    for (int l = 0; l < D; ++l) xc[l] = a.coords[l * N + min(sub, N - 1)];
 
     // ---- owner set-up: this lane owns packed slots sub, sub+G, ... of its block --------
     // per-slot learning rate (0 = not trained) and l1 regulariser constant stay in registers;
@@ -585,9 +590,6 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     }
                 }
             }
-            float xc[D];
-#pragma unroll
-            for (int l = 0; l < D; ++l) xc[l] = s_coords[l * N + sub];     // pixel i = 0 of the lane
             if (HL > 0) hoist_const<D, C, K, HL>(R, xc);
             if (has_lw) pixel_loop_train<D, C, K, true, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
             else pixel_loop_train<D, C, K, false, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
@@ -700,10 +702,10 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     const int b = valid_b ? b_raw : B - 1;
 
     float* s_coords = lds + T::off_coords();
-    float* s_par = lds + T::off_par(N) + lb * Lt::LP_STRIDE;
-    float* s_scratch = lds + T::off_scratch(N) + wave * (T::CH * T::ROW);
-    const float* s_tgt = lds + T::off_tgt(N) + lb * (C * N);
-    const float* s_lw = lds + T::off_lw(N) + lb * N;
+    float* s_par = lds + T::off_par(N, D) + lb * Lt::LP_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N, D) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N, D) + lb * (C * N);
+    const float* s_lw = lds + T::off_lw(N, D) + lb * N;
     const bool has_lw = a.loss_w != nullptr;
 
     stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
@@ -908,10 +910,11 @@ __global__ void reduce_scalars_kernel(ReduceArgs a) {
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
     auto kern = fit_kernel<D, C, K, G, WAVES, 0>;
-    if (hoist == 1) kern = fit_kernel<D, C, K, G, WAVES, 1>;
-    if (D == 3 && hoist >= 2) kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>;
+    int hl = 0;
+    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
+    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -939,7 +942,7 @@ int fit_occupancy(int N, bool has_lw) {
     using T = Tile<D, C, K, G, WAVES>;
     int nb = 0;
     auto kern = fit_kernel<D, C, K, G, WAVES, 1>;
-    const size_t shm = T::bytes(N, has_lw);
+    const size_t shm = T::bytes(N, has_lw, D - 1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, shm) != hipSuccess) return -1;
     return nb * WAVES;       // resident wavefronts per CU
