@@ -81,6 +81,52 @@ def from_planar(arr: np.ndarray, block_shape: Sequence[int]) -> np.ndarray:
     return np.ascontiguousarray(arr.transpose(0, 2, 1)).reshape((B,) + tuple(block_shape) + (C,))
 
 
+def get_batch_shape(desired_batches: int, joint_domain_shape: Sequence[int]) -> Tuple[int, ...]:
+    """Smoe.get_batch_shape (smoe.py:2459-2543): the block shape used when no ``batch_size`` is given.
+    Every axis is divided by one of its divisors so that the number of batches is the smallest
+    possible count >= ``desired_batches``; among those the divisor tuple with the smallest sum
+    (most cube-like split) wins, first hit in the reference's enumeration order on ties.
+    ``joint_domain_shape`` = image shape incl. the trailing (d + C) axis, which is never split."""
+    def divisors(n):
+        factors = {}
+        nn, i = n, 2
+        while i * i <= nn:
+            while nn % i == 0:
+                factors[i] = factors.get(i, 0) + 1
+                nn //= i
+            i += 1
+        if nn > 1:
+            factors[nn] = 1
+        primes = list(factors.keys())
+
+        def generate(k):
+            if k == len(primes):
+                yield 1
+            else:
+                for factor in generate(k + 1):
+                    p_i = 1
+                    for _ in range(factors[primes[k]] + 1):
+                        yield factor * p_i
+                        p_i *= primes[k]
+        return list(generate(0))
+
+    import itertools
+    shape = [int(v) for v in joint_domain_shape]
+    factors = [divisors(n) for n in shape[:-1]] + [[1]]
+    if len(shape) > 4:                                   # light-field hack of the reference (smoe.py:2507-2509)
+        factors[0] = [1]
+        factors[1] = [1]
+    shapes = list(itertools.product(*factors))
+    possible = np.array([float(np.prod(sh[:-1])) for sh in shapes])
+    diff = possible - desired_batches
+    diff[diff < 0] = np.inf
+    aimed = possible[int(np.argmin(diff))]
+    cand = [shapes[i] for i in np.where(possible == aimed)[0]]
+    sums = [np.sum(divs[2:3]) if len(divs) > 4 else np.sum(divs) for divs in cand]
+    divs = cand[int(np.argmin(sums))]
+    return tuple(int(shape[i] / divs[i]) for i in range(len(shape)))
+
+
 # ------------------------------------------------------------------------------------
 # the reference's initialisers, per block
 # ------------------------------------------------------------------------------------

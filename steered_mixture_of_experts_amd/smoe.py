@@ -105,7 +105,8 @@ class Smoe:
         # -- block shape (smoe.py:231-247) -----------------------------------------------
         d = self.dim_domain
         if batch_size is None or batch_size[0] is None:
-            bs = tuple(image.shape[:d])                 # one block = the whole (small) image
+            # smoe.py:229,243: block shape from the desired number of batches (1 -> the whole image)
+            bs = blk.get_batch_shape(start_batches, tuple(image.shape[:d]) + (d + image.shape[-1],))[:-1]
         elif len(batch_size) == d:
             bs = tuple(int(b) for b in batch_size)
         elif len(batch_size) == 1:
@@ -549,7 +550,7 @@ class SharedSmoe:
         self.only_y_gamma = self.ssim_opt = self.use_diff_center = self.radial_as = False
         self.overlap = 0
         if batch_size is None or batch_size[0] is None:
-            bs = tuple(image.shape[:d])
+            bs = blk.get_batch_shape(start_batches, tuple(image.shape[:d]) + (d + image.shape[-1],))[:-1]
         elif len(batch_size) == d:
             bs = tuple(int(b) for b in batch_size)
         elif len(batch_size) == 1:

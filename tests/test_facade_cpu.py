@@ -205,3 +205,11 @@ def test_shared_kernel_facade_matches_the_numpy_restatement():
         SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[10, 16], engine_factory=OracleSharedEngine)
     with pytest.raises(NotImplementedError):
         SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[16, 16], overlap_of_batches=2, engine_factory=OracleSharedEngine)
+
+
+def test_start_batches_selects_the_block_shape():
+    img = _image(64, 64)
+    s = Smoe(img, kernels_per_dim=[2, 2], start_batches=16, batch_size=[None], engine_factory=OracleEngine)
+    assert s.batch_size_valued == (16, 16) and s.num_blocks == 16            # get_batch_shape, smoe.py:229,243
+    s1 = Smoe(img[:16, :16], kernels_per_dim=[2, 2], engine_factory=OracleEngine)
+    assert s1.batch_size_valued == (16, 16) and s1.num_blocks == 1

@@ -78,3 +78,17 @@ def test_shard_ranges_partition_the_blocks():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(R - 1))
             assert max(hi - lo for lo, hi in spans) <= -(-B // R) if B else True
     assert sdist.world() == (0, 1)
+
+
+def test_get_batch_shape_divisor_search():
+    # smoe.py:2459-2543: smallest batch count >= desired, most cube-like split, trailing axis untouched
+    assert blk.get_batch_shape(1, (512, 512, 3)) == (512, 512, 3)
+    assert blk.get_batch_shape(1024, (512, 512, 3)) == (16, 16, 3)
+    assert blk.get_batch_shape(1000, (512, 512, 3)) == (16, 16, 3)          # 1024 is the next reachable count
+    assert blk.get_batch_shape(2, (512, 512, 3)) in ((256, 512, 3), (512, 256, 3))
+    assert blk.get_batch_shape(4, (512, 512, 3)) == (256, 256, 3)
+    assert blk.get_batch_shape(6, (48, 36, 5)) == (16, 18, 5) or np.prod(np.array((48, 36)) / np.array(blk.get_batch_shape(6, (48, 36, 5))[:2])) == 6
+    s = blk.get_batch_shape(8, (64, 64, 16, 6))
+    assert s[-1] == 6 and (64 // s[0]) * (64 // s[1]) * (16 // s[2]) == 8 and s == (32, 32, 8, 6)
+    s = blk.get_batch_shape(7, (30, 20, 4))                                   # 7 is not reachable: next is 8
+    assert (30 // s[0]) * (20 // s[1]) == 8 and 30 % s[0] == 0 and 20 % s[1] == 0
