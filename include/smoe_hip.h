@@ -68,6 +68,7 @@ typedef struct smoe_config {
     float   pis_l1;             /* pis_l1 * sum(pis) / start_pis          smoe.py:1027                  */
     float   u_l1;               /* u_l1 * sum(diag A)                     smoe.py:1044                  */
     int32_t start_pis;          /* normaliser K0 of the l1 term           smoe.py:264,1025              */
+    int32_t only_y_gamma;       /* slopes only for channel 0 (gamma_mask) smoe.py:725-729               */
 } smoe_config;
 
 /* Parameter set in the reference's get_params() layout (smoe.py:1795-1800) with a
@@ -180,6 +181,7 @@ typedef struct smoe_shared_config {
     int32_t use_determinant, use_yuv, train_pis, train_gammas, train_musx;
     float   lr_expert, lr_pis, lr_steer, beta1, beta2, adam_eps, grad_clip, pis_l1, u_l1;
     int32_t start_pis;
+    int32_t only_y_gamma;
 } smoe_shared_config;
 
 typedef struct smoe_shared_context* smoe_shared_handle;

@@ -18,7 +18,8 @@ class OracleCfg(C.Structure):
                 ("use_yuv", C.c_int32), ("train_pis", C.c_int32), ("train_gammas", C.c_int32),
                 ("train_musx", C.c_int32), ("lr_expert", C.c_float), ("lr_pis", C.c_float),
                 ("lr_steer", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-                ("grad_clip", C.c_float), ("pis_l1", C.c_float), ("u_l1", C.c_float), ("start_pis", C.c_int32)]
+                ("grad_clip", C.c_float), ("pis_l1", C.c_float), ("u_l1", C.c_float), ("start_pis", C.c_int32),
+                ("only_y_gamma", C.c_int32)]
 
 
 _lib = None
@@ -44,6 +45,7 @@ def _cfg(cfg):
     c.beta1, c.beta2, c.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
     c.grad_clip = cfg.grad_clip or 0.0
     c.pis_l1, c.u_l1, c.start_pis = cfg.pis_l1, cfg.u_l1, cfg.k0
+    c.only_y_gamma = int(getattr(cfg, 'only_y_gamma', False))
     return c
 
 

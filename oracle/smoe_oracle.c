@@ -36,6 +36,7 @@ typedef struct oracle_cfg {
     float grad_clip;
     float pis_l1, u_l1;
     int32_t start_pis;
+    int32_t only_y_gamma;       /* smoe.py:725-729 */
 } oracle_cfg;
 
 typedef struct grads_t {
@@ -55,6 +56,7 @@ static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, con
     const float levels = two_p - 1.0f;
     const float scale = 1.0f / levels, inv_scale = 1.0f / scale, nudged_max = levels * scale;
     const float n_dis = (float)sqrt(pow(2.0 * M_PI, (double)D));       /* smoe.py:812 */
+    const int y_only = c->only_y_gamma && c->use_yuv && c->train_gammas; /* smoe.py:725 */
     float A[MAXK][MAXD][MAXD], coef[MAXK];
     int act[MAXK];
     float cw[MAXC];
@@ -103,7 +105,7 @@ static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, con
             if (M) infl |= 1u << k;                                    /* smoe.py:829 */
             for (int ch = 0; ch < C; ++ch) {                           /* smoe.py:840-848 */
                 float ee = nu[k * C + ch];
-                if (c->train_gammas)
+                if (c->train_gammas && !(y_only && ch > 0))
                     for (int l = 0; l < D; ++l) ee += ga[(k * D + l) * C + ch] * x[l];
                 e[k][ch] = ee;
                 y[ch] += wt[k] * ee;
@@ -143,7 +145,7 @@ static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, con
             for (int ch = 0; ch < C; ++ch) {
                 const float wg = wt[k] * G[ch];
                 g->nu[k][ch] += wg;
-                if (c->train_gammas)
+                if (c->train_gammas && !(y_only && ch > 0))
                     for (int l = 0; l < D; ++l) g->ga[k][l][ch] += wg * x[l];
             }
         }
@@ -244,7 +246,7 @@ int smoe_oracle_fit(const oracle_cfg* c, int B, const float* coords, const float
                             }
                         }
                         if (c->train_gammas && c->lr_expert != 0.0f)
-                            for (int ch = 0; ch < C; ++ch) {
+                            for (int ch = 0; ch < ((c->only_y_gamma && c->use_yuv) ? 1 : C); ++ch) {
                                 const int gg = (k * D + l2) * C + ch;
                                 adam_one(&ga[gg], &m[4][o4 + gg], &v[4][o4 + gg], g.ga[k][l2][ch], c->lr_expert, c, b1p, b2p);
                             }

@@ -67,6 +67,7 @@ class OracleConfig:
     pis_l1: float = 0.0                   # smoe.py:1027
     u_l1: float = 0.0                     # smoe.py:1044
     start_pis: Optional[int] = None       # smoe.py:264 (K0 of the l1 normaliser)
+    only_y_gamma: bool = False            # smoe.py:725-729 (slopes only for channel 0)
 
     @property
     def dim(self) -> int:
@@ -218,6 +219,10 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     mu = p["musX"].astype(T)
     nu = p["nu_e"].astype(T)
     gam = p["gamma_e"].astype(T)
+    y_only = cfg.only_y_gamma and cfg.use_yuv and cfg.train_gammas            # smoe.py:725
+    if y_only:
+        gam = gam.copy()
+        gam[..., 1:] = T(0)                                  # qgamma_e * gamma_mask
     A = _steering(p, T)                                      # (B,K,d,d)
     lw = np.ones((B, N), dtype=T) if loss_w is None else loss_w.astype(T)
 
@@ -314,6 +319,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     g_mu = np.einsum("bkn,bknl->bkl", u, Az)
     if not cfg.train_gammas:
         g_gam = np.zeros_like(g_gam)
+    if y_only:
+        g_gam[..., 1:] = T(0)
     out["grads"] = {"pis": g_pi, "musX": g_mu, "A_diagonal": g_Adiag, "A_corr": g_Acorr,
                     "gamma_e": g_gam, "nu_e": g_nu}
     return out

@@ -174,6 +174,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     kc.inv_n_dis = 1.0f / kc.n_dis;
     kc.use_det = cfg->use_determinant ? 1 : 0;
     kc.train_gammas = cfg->train_gammas ? 1 : 0;
+    kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;   // smoe.py:725
     *out = h;
     return SMOE_OK;
 }
@@ -450,6 +451,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     kc.inv_n_dis = 1.0f / kc.n_dis;
     kc.use_det = cfg->use_determinant ? 1 : 0;
     kc.train_gammas = cfg->train_gammas ? 1 : 0;
+    kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;
     *out = h;
     return SMOE_OK;
 }
@@ -518,7 +520,7 @@ int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, 
     a.b1p = s->beta1_power; a.b2p = s->beta2_power; a.beta1 = c.beta1; a.beta2 = c.beta2; a.eps = c.adam_eps;
     a.clip = c.grad_clip;
     a.lr_expert = c.lr_expert; a.lr_pis = c.lr_pis; a.lr_steer = c.lr_steer;
-    a.train_pis = c.train_pis; a.train_musx = c.train_musx; a.train_gammas = c.train_gammas; a.use_det = c.use_determinant;
+    a.train_pis = c.train_pis; a.train_musx = c.train_musx; a.train_gammas = c.train_gammas; a.use_det = c.use_determinant; a.only_y_gamma = h->kc.only_y_gamma;
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
     a.reg_u = c.u_l1;
     HIP_TRY(smoe::launch_shared_adam(a, c.dim, c.channels, (hipStream_t)stream), "smoe_shared_apply launch");

@@ -23,6 +23,7 @@ struct KernelConsts {
     float inv_n_dis;    // 1 / n_dis
     int use_det;        // smoe.py:809
     int train_gammas;   // smoe.py:841
+    int only_y_gamma;   // gamma_mask: slopes only for channel 0 (smoe.py:725-729)
 };
 
 struct FitArgs {
@@ -120,7 +121,7 @@ struct SharedAdamArgs {
     int K;
     float b1p, b2p, beta1, beta2, eps, clip;
     float lr_expert, lr_pis, lr_steer;
-    int train_pis, train_musx, train_gammas, use_det;
+    int train_pis, train_musx, train_gammas, use_det, only_y_gamma;
     float reg_pi, reg_u;
 };
 

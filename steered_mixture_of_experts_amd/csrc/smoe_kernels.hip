@@ -163,6 +163,12 @@ struct BlockRegs {
 #pragma unroll
                 for (int i = 0; i < D * C; ++i) P[k * Lt::PK + Lt::O_GA + i] = 0.0f;
             }
+            if (kc.only_y_gamma) {           // smoe.py:725-729: qgamma_e * gamma_mask (channel 0 only)
+#pragma unroll
+                for (int l = 0; l < D; ++l)
+#pragma unroll
+                    for (int c = 1; c < C; ++c) P[k * Lt::PK + Lt::O_GA + l * C + c] = 0.0f;
+            }
         }
     }
 };
@@ -549,6 +555,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             if (tensor == 0 && !a.train_pis) r = 0.0f;
             if (tensor == 1 && !a.train_musx) r = 0.0f;
             if (tensor == 4 && !a.kc.train_gammas) r = 0.0f;
+            if (tensor == 4 && a.kc.only_y_gamma && (off % C) != 0) r = 0.0f;   // masked slopes get zero gradient
             lr[s] = r;
             reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? a.reg_u : 0.0f);   // smoe.py:1027,1044
         } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {

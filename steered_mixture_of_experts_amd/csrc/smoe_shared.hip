@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) r[L::O_NU + c] = a.p.nu_e[(size_t)k * C + c];
 #pragma unroll
-            for (int i = 0; i < D * C; ++i) r[L::O_GA + i] = a.kc.train_gammas ? a.p.gamma_e[(size_t)k * D * C + i] : 0.0f;
+            for (int i = 0; i < D * C; ++i)
+                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? a.p.gamma_e[(size_t)k * D * C + i] : 0.0f;
         }
         __syncthreads();
     };
@@ -425,6 +426,7 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
 #pragma unroll
         for (int i = 0; i < D * C; ++i) {
             const size_t o = (size_t)k * D * C + i;
+            if (a.only_y_gamma && (i % C) != 0) continue;
             adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], r[L::R_SWGX + i], a.lr_expert, a);
         }
     }

@@ -40,6 +40,7 @@ class EngineConfig:
     pis_l1: float = 0.0
     u_l1: float = 0.0
     start_pis: int = 0
+    only_y_gamma: bool = False
 
     @property
     def dim(self) -> int:
@@ -102,6 +103,7 @@ class BlockEngine:
         c.grad_clip = cfg.grad_clip or 0.0
         c.pis_l1, c.u_l1 = cfg.pis_l1, cfg.u_l1
         c.start_pis = cfg.start_pis or cfg.kernels
+        c.only_y_gamma = int(cfg.only_y_gamma)
         self._c = c
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_create(C.byref(self._h), C.byref(c)))
@@ -255,6 +257,7 @@ class SharedConfig:
     pis_l1: float = 0.0
     u_l1: float = 0.0
     start_pis: int = 0
+    only_y_gamma: bool = False
 
     @property
     def dim(self) -> int:
@@ -283,6 +286,7 @@ class SharedEngine:
         c.beta1, c.beta2, c.adam_eps = cfg.beta1, cfg.beta2, cfg.adam_eps
         c.grad_clip, c.pis_l1, c.u_l1 = cfg.grad_clip or 0.0, cfg.pis_l1, cfg.u_l1
         c.start_pis = cfg.start_pis or cfg.kernels
+        c.only_y_gamma = int(cfg.only_y_gamma)
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_shared_create(C.byref(self._h), C.byref(c)))
         self.num_batches = int(self.lib.smoe_shared_num_batches(self._h))

@@ -56,9 +56,9 @@ class Smoe:
                  only_rec_from_checkpoint=False, loss_mask=None, device=None, engine_factory=None):
         # -- options outside the hot path: refuse loudly ---------------------------------
         unsupported = {
-            "use_diff_center": use_diff_center, "radial_as": radial_as, "ssim_opt": ssim_opt,
+            "radial_as": radial_as, "ssim_opt": ssim_opt,
             "train_svs": train_svs, "train_trafo": train_trafo, "train_inverse_cov": train_inverse_cov,
-            "only_y_gamma": only_y_gamma, "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
+            "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
         }
         for name, val in unsupported.items():
             if val:
@@ -81,7 +81,7 @@ class Smoe:
         self.num_pixel = int(np.prod(image.shape[:self.dim_domain]))    # smoe.py:228
         self.precision = precision
         self.use_yuv = bool(use_yuv) and image.shape[-1] == 3           # smoe_test.py:41-44
-        self.only_y_gamma = only_y_gamma
+        self.only_y_gamma = bool(only_y_gamma) and self.use_yuv         # smoe_test.py:43-44
         self.ssim_opt = ssim_opt
         self.use_diff_center = use_diff_center
         self.radial_as = radial_as
@@ -149,6 +149,11 @@ class Smoe:
             K = p0["pis"].shape[1]
             self.musX_init = blk.gen_domain_grid(kpd, d)
         self.kernels = K
+        # use_diff_center (smoe.py:390-394,746-747): the trained variable is the OFFSET from the kernel
+        # grid (initialised to zero); the engine works on grid + offset, the getters subtract the grid.
+        self._mus_grid = None
+        if use_diff_center:
+            self._mus_grid = np.ascontiguousarray(p0["musX"]).copy()
         self.start_pis = K                                               # smoe.py:264, per block
         self.kernel_count = K * self.num_blocks
 
@@ -210,7 +215,7 @@ class Smoe:
             beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999,
             adam_eps=o1._epsilon if o1 else 1e-8,
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
-            start_pis=self.kernels)
+            start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma))
         key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
         key = repr(key)
         if key != self._engine_key:
@@ -405,7 +410,10 @@ class Smoe:
 
     # -- getters (smoe.py:1795-1888) ------------------------------------------------------------
     def _gather_params(self, p: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
-        return {k: sdist.allgather_blocks(v.cpu().numpy().copy(), self.num_blocks) for k, v in p.items()}
+        out = {k: v.cpu().numpy().copy() for k, v in p.items()}
+        if self._mus_grid is not None:                     # use_diff_center: report the trained offsets
+            out["musX"] = out["musX"] - self._mus_grid
+        return {k: sdist.allgather_blocks(v, self.num_blocks) for k, v in out.items()}
 
     def get_params(self):
         return self._gather_params(self._params)

@@ -38,7 +38,7 @@ class OracleEngine:
             train_pis=cfg.train_pis, train_gammas=cfg.train_gammas, train_musx=cfg.train_musx,
             lr_expert=cfg.lr_expert, lr_pis=cfg.lr_pis, lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2,
             adam_eps=cfg.adam_eps, grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1,
-            start_pis=cfg.start_pis or cfg.kernels)
+            start_pis=cfg.start_pis or cfg.kernels, only_y_gamma=getattr(cfg, 'only_y_gamma', False))
         self.coords = np.ascontiguousarray(o.block_coords(cfg.block_shape).T)
 
     def close(self):

@@ -109,7 +109,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
     for kw in ({"ssim_opt": True}, {"quantization_mode": 2}, {"overlap_of_batches": 2}, {"add_kernel_slots": 4},
-               {"train_svs": True}, {"radial_as": True}, {"train_inverse_cov": True}, {"use_diff_center": True}):
+               {"train_svs": True}, {"radial_as": True}, {"train_inverse_cov": True}, {"quantization_mode": 3}):
         with pytest.raises(NotImplementedError):
             Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
     with pytest.raises(AssertionError):
@@ -213,3 +213,25 @@ def test_start_batches_selects_the_block_shape():
     assert s.batch_size_valued == (16, 16) and s.num_blocks == 16            # get_batch_shape, smoe.py:229,243
     s1 = Smoe(img[:16, :16], kernels_per_dim=[2, 2], engine_factory=OracleEngine)
     assert s1.batch_size_valued == (16, 16) and s1.num_blocks == 1
+
+
+def test_only_y_gamma_and_use_diff_center():
+    img = _image(32, 32, C=3, seed=9)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, only_y_gamma=True,
+             use_diff_center=True, engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    assert s.only_y_gamma and np.array_equal(s.get_params()["musX"], np.zeros((4, 4, 2), np.float32))
+    s.train(6, val_iter=3)
+    p = s.get_params()
+    assert np.abs(p["gamma_e"][..., 0]).max() > 0 and not p["gamma_e"][..., 1:].any()      # smoe.py:725-729
+    assert 0 < np.abs(p["musX"]).max() < 0.05                                               # offsets, not centres
+    # the same fit without use_diff_center: centres = grid + offsets
+    t = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, only_y_gamma=True,
+             engine_factory=OracleEngine)
+    t.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+    t.train(6, val_iter=3)
+    grid = blk.gen_domain_grid([2, 2], 2).astype(np.float32)
+    assert np.allclose(t.get_params()["musX"], grid[None] + p["musX"], atol=1e-7)
+    # only_y_gamma is dropped when the image is not YUV (smoe_test.py:41-44)
+    g = Smoe(img[..., :1], kernels_per_dim=[2, 2], batch_size=[16, 16], only_y_gamma=True, engine_factory=OracleEngine)
+    assert not g.only_y_gamma

@@ -378,3 +378,35 @@ def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     for name in ("nu_e", "musX", "gamma_e"):
         assert np.abs(got[name] - p_ref[name]).max() < 2e-5, name
     eng.close()
+
+
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_only_y_gamma(tiling):
+    """gamma_mask (smoe.py:725-729): slopes act and train only for channel 0."""
+    shape, C, kpd = (16, 16), 3, [2, 2]
+    B = 11
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, True, B, 99, only_y_gamma=True)
+    active = np.ones((B, K), dtype=bool)
+    eng = _engine(shape, C, K, use_yuv=True, only_y_gamma=True)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float64, want_grads=True, q_override=recon)
+    plain = o.forward(p, tgt, coords, active, o.OracleConfig(block_shape=shape, channels=C, kernels=K, use_yuv=True),
+                      None, np.float64)
+    assert np.abs(plain["y"] - ref["y"]).max() > 1e-3                 # the mask changes the blend
+    assert np.allclose(fw["loss"].cpu().numpy(), ref["loss"], rtol=3e-5)
+    st = eng.new_adam_state(dp)
+    before = dp["gamma_e"].cpu().numpy().copy()
+    eng.fit(T, dp, st, act, 1)
+    torch.cuda.synchronize()
+    m = _to_host(st.m)
+    for name in o.PARAM_NAMES:
+        scale = np.abs(ref["grads"][name]).max() + 1e-30
+        assert np.abs(m[name] / 0.1 - ref["grads"][name]).max() / scale < 3e-5, name
+    after = dp["gamma_e"].cpu().numpy()
+    assert np.array_equal(after[..., 1:], before[..., 1:]) and not np.array_equal(after[..., 0], before[..., 0])
+    eng.close()
