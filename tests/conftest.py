@@ -25,3 +25,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries_present():
+    """The .so files are git-ignored build artefacts: build them in-tree if a fresh checkout lacks them
+    (hipcc cross-compiles without a GPU; the oracle library is plain gcc)."""
+    import subprocess
+    lib = os.path.join(ROOT, "steered_mixture_of_experts_amd", "libsmoe_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "steered_mixture_of_experts_amd", "csrc"), "-j4"])
+    ora = os.path.join(ROOT, "oracle", "libsmoe_oracle.so")
+    if not os.path.exists(ora):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    yield
