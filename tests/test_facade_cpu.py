@@ -235,3 +235,37 @@ def test_only_y_gamma_and_use_diff_center():
     # only_y_gamma is dropped when the image is not YUV (smoe_test.py:41-44)
     g = Smoe(img[..., :1], kernels_per_dim=[2, 2], batch_size=[16, 16], only_y_gamma=True, engine_factory=OracleEngine)
     assert not g.only_y_gamma
+
+
+def test_training_cli_mirrors_the_reference_flags(tmp_path):
+    import steered_mixture_of_experts_amd.smoe as smod
+    import steered_mixture_of_experts_amd.smoe_test as cli
+    from fake_engine import OracleSharedEngine
+    img = _image(32, 48)
+    np.save(tmp_path / "img.npy", np.uint8(np.round(img * 255)))
+    parser = cli.build_parser()
+    d = vars(parser.parse_args(["-i", "x", "-r", "y"]))
+    # defaults of the reference CLI (smoe_test.py:262-352) for everything on the hot path
+    assert d["iterations"] == 10000 and d["validation_iterations"] == 100 and d["kernels_per_dim"] == [12]
+    assert d["base_lr"] == 0.001 and d["lr_div"] == 100 and d["lr_mult"] == 1000 and d["use_determinant"] is True
+    assert d["bit_depths"] == [20, 18, 6, 10, 10] and d["batch_size"] == [None] and d["train_inverse_cov"] is False
+    f1, f2 = smod._default_engine_factory, smod._default_shared_factory
+    smod._default_engine_factory = lambda cfg, device: OracleEngine(cfg, device)
+    smod._default_shared_factory = lambda cfg, device: OracleSharedEngine(cfg, device)
+    try:
+        out = str(tmp_path / "res")
+        s = cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "2", "-bz", "16", "16",
+                                        "-n", "4", "-v", "2"]))
+        assert s.num_blocks == 6 and s.optimizer2._lr == 1e-5 and s.optimizer3._lr == 1.0
+        cp = utils.load_checkpoint(out + "/params_last.pkl")
+        assert cp["params"]["nu_e"].shape == (6, 4, 1) and [i for i, _ in cp["losses"]] == [0, 2, 4]
+        assert np.load(out + "/reconstruction.npy").shape == (32, 48, 1)
+        g = cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "3", "-bz", "16", "16",
+                                        "-n", "2", "-v", "2", "--mode", "shared"]))
+        assert g.kernels == 9 and g.num_batches == 6
+        with pytest.raises(NotImplementedError):
+            cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-ssim", "true"]))
+        with pytest.raises(NotImplementedError):
+            cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-is", "100"]))
+    finally:
+        smod._default_engine_factory, smod._default_shared_factory = f1, f2
