@@ -227,3 +227,32 @@ def test_large_configs_against_the_c_oracle_on_a_sample(name, img_shape, bs, C, 
 def test_smoke_entry_point():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_end_to_end_fit_quality_on_a_smooth_image():
+    """Functional check through the facades: with a gentle steering learning rate (lr_mult = 10 instead
+    of the reference CLI's 1000, which random-walks the steering diagonals through zero on small
+    domains -- DESIGN.md section 5) both modes converge and gain several dB."""
+    from steered_mixture_of_experts_amd.smoe import Adam, SharedSmoe, Smoe
+    rng = np.random.default_rng(7)
+    H = W = 128
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    img = 0.35 + 0.3 * xx - 0.15 * yy
+    for _ in range(8):
+        cy, cx, s, a = rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0.05, 0.25), rng.uniform(-0.3, 0.3)
+        img += a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+    img += 0.2 * (xx + 0.5 * yy > 0.9) + rng.normal(scale=1.5 / 255, size=img.shape)
+    img = (np.round(np.clip(img, 0, 1) * 255).astype(np.uint8).astype(np.float32) / np.float32(255.))[..., None]
+    b = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True)
+    b.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+    p0 = b.get_psnr()
+    b.train(300, val_iter=100)
+    assert b.get_psnr() > p0 + 4.0, (p0, b.get_psnr())
+    assert [i for i, _ in b.get_losses()] == [0, 100, 200, 300]
+    assert b.get_losses()[-1][1] < b.get_losses()[0][1]
+    s = SharedSmoe(img, kernels_per_dim=[8, 8], batch_size=[32, 32], use_determinant=True)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+    q0 = s.get_psnr()
+    s.train(300, val_iter=100)
+    assert s.get_psnr() > q0 + 4.0, (q0, s.get_psnr())
+    assert np.diagonal(s.get_params()["A_diagonal"], axis1=-2, axis2=-1).min() > 0
