@@ -165,7 +165,9 @@ int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
  * kernels over the [0,1]^d image domain; the image is cut into batches (sliding_window,
  * smoe.py:18-35); every batch evaluates the kernels of its kernel list (smoe.py:738-753); the
  * gradients of all batches of a pass are accumulated (smoe.py:1148-1150) and one ApplyAdam step
- * follows (smoe.py:1788).  overlap_of_batches = 0 only.
+ * follows (smoe.py:1788).  overlap_of_batches > 0 adds the halo: the window's extra pixels only take
+ * part in the kernel-list influence test (their loss is cropped, smoe.py:909-923); window pixels outside
+ * the image carry all-zero coordinates (np.pad of the joint domain, smoe.py:21,28).
  *   target [NB,C,Nb] (batch-planar, as the block layout)   params: get_params() layout, leading K
  *   lists  [NB, KW] uint32 bitmaps, KW = smoe_shared_list_words(h) = ceil(K/32)
  * For multi-GPU the host layer shards the BATCHES: every call takes the range
@@ -182,6 +184,7 @@ typedef struct smoe_shared_config {
     float   lr_expert, lr_pis, lr_steer, beta1, beta2, adam_eps, grad_clip, pis_l1, u_l1;
     int32_t start_pis;
     int32_t only_y_gamma;
+    int32_t overlap;                    /* overlap_of_batches (smoe.py:244), pixels per side */
 } smoe_shared_config;
 
 typedef struct smoe_shared_context* smoe_shared_handle;

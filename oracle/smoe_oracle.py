@@ -472,6 +472,23 @@ def global_batch_coords(image_shape: Sequence[int], batch_shape: Sequence[int], 
     return grids.reshape(split + [d]).transpose(perm + [2 * d]).reshape(int(np.prod(g)), -1, d)
 
 
+def global_halo_coords(image_shape: Sequence[int], batch_shape: Sequence[int], overlap: int, dtype=np.float32):
+    """(NB, Next, d) coordinates of the EXTENDED windows the reference iterates when
+    overlap_of_batches > 0 (sliding_window, smoe.py:18-35): the joint domain is zero-padded by
+    ``overlap`` on every side, so a window pixel outside the image has ALL coordinates 0."""
+    d = len(batch_shape)
+    axes = [np.linspace(0, 1, int(s)).astype(np.float32).astype(dtype) for s in image_shape]
+    grids = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1)
+    pad = [(overlap, overlap)] * d + [(0, 0)]
+    padded = np.pad(grids, pad, mode="constant", constant_values=0)
+    out = []
+    ranges = [range(0, int(s), int(b)) for s, b in zip(image_shape, batch_shape)]
+    for org in itertools.product(*ranges):
+        sl = tuple(slice(o, o + int(b) + 2 * overlap) for o, b in zip(org, batch_shape))
+        out.append(padded[sl].reshape(-1, d))
+    return np.stack(out)
+
+
 def shared_init_params(image: np.ndarray, kernels_per_dim: Sequence[int], normalize_pis: bool = True):
     """Smoe.__init__ without init_params for the whole image (smoe.py:260-262): parameters with a
     leading axis of 1 (one model)."""
@@ -482,7 +499,7 @@ def _bcast(p, NB):
     return {k: np.broadcast_to(v, (NB,) + v.shape[1:]) for k, v in p.items()}
 
 
-def shared_pass(p, target, coords, lists, cfg: OracleConfig, dtype=np.float32, want_grads=False):
+def shared_pass(p, target, coords, lists, cfg: OracleConfig, dtype=np.float32, want_grads=False, halo_coords=None):
     """One run_batched pass (smoe.py:1606-1793) in shared-kernel mode.  p: leading axis 1;
     target (NB,Nb,C); coords (NB,Nb,d); lists (NB,K) bool.  Returns the per-batch forward dict plus
     ``loss_val``/``mse_val`` (pixel-weighted means, smoe.py:1758-1759), ``lists_new`` (1763-1766)
@@ -492,12 +509,19 @@ def shared_pass(p, target, coords, lists, cfg: OracleConfig, dtype=np.float32, w
     f["loss_val"] = float(np.mean(f["loss"]))                       # equal-size batches
     f["mse_val"] = float(np.mean(f["mse_op"]))
     f["lists_new"] = f["active_new"]
+    if halo_coords is not None:
+        # overlap_of_batches > 0: the graph runs on the extended window, the loss (and with it every
+        # gradient) is cropped to the interior (smoe.py:909-923); what the halo changes is the
+        # influence test over the whole window (smoe.py:829,836) -> the new kernel list
+        fe = forward(_bcast(p, NB), np.zeros(halo_coords.shape[:2] + (target.shape[2],), dtype), halo_coords, lists,
+                     cfg, None, dtype)
+        f["lists_new"] = fe["active_new"]
     if want_grads:
         f["grads"] = {k: np.sum(v, axis=0, keepdims=True) for k, v in f["grads"].items()}
     return f
 
 
-def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):
+def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):   # coords: the (extended) windows
     """update_kernel_list (smoe.py:2287-2365): per batch, probes = {min,max,mid}^d of the batch's
     coordinates; list |= (pis>0) & any_probe(maha < 800)."""
     T = dtype
@@ -517,7 +541,7 @@ def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):
 
 
 def shared_fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int = 100, ukl_iter=None,
-               dtype=np.float32):
+               dtype=np.float32, halo_coords=None):
     """Smoe.train in shared-kernel mode (smoe.py:1485-1603): iteration-0 eval pass, per iteration a
     train pass (prune lists) + one Adam step on the accumulated gradients, readmission every
     ukl_iter, eval + best snapshot every val_iter."""
@@ -529,20 +553,20 @@ def shared_fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int
     p = {k: v.astype(T) for k, v in p.items()}
     state = new_adam_state(p)
     lists = np.ones((NB, K), dtype=bool)                              # smoe.py:315
-    f0 = shared_pass(p, target, coords, lists, cfg, T)
+    f0 = shared_pass(p, target, coords, lists, cfg, T, halo_coords=halo_coords)
     lists = f0["lists_new"]
     hist = {"iter": [0], "loss": [f0["loss_val"]], "mse": [f0["mse_val"]]}
     best, best_loss = {k: v.copy() for k, v in p.items()}, f0["loss_val"]
     train_losses = []
     for i in range(1, n_iters + 1):
-        f = shared_pass(p, target, coords, lists, cfg, T, want_grads=True)
+        f = shared_pass(p, target, coords, lists, cfg, T, want_grads=True, halo_coords=halo_coords)
         lists = f["lists_new"]
         p = adam_step(p, f["grads"], state, cfg, T)
         train_losses.append(f["loss_val"])
         if i % ukl_iter == 0:
-            lists = shared_readmit(p, lists, coords, cfg, T)
+            lists = shared_readmit(p, lists, coords if halo_coords is None else halo_coords, cfg, T)
         if i % val_iter == 0:
-            fv = shared_pass(p, target, coords, lists, cfg, T)
+            fv = shared_pass(p, target, coords, lists, cfg, T, halo_coords=halo_coords)
             lists = fv["lists_new"]
             if fv["loss_val"] < best_loss:
                 best_loss, best = fv["loss_val"], {k: v.copy() for k, v in p.items()}

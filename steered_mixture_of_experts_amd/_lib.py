@@ -51,7 +51,7 @@ class SmoeSharedConfig(C.Structure):
         ("train_gammas", C.c_int32), ("train_musx", C.c_int32), ("lr_expert", C.c_float), ("lr_pis", C.c_float),
         ("lr_steer", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
         ("grad_clip", C.c_float), ("pis_l1", C.c_float), ("u_l1", C.c_float), ("start_pis", C.c_int32),
-        ("only_y_gamma", C.c_int32),
+        ("only_y_gamma", C.c_int32), ("overlap", C.c_int32),
     ]
 
 

@@ -345,7 +345,9 @@ void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
         a.axis_off[l] = h->axis_off[l];
         a.batch_shape[l] = (l < c.dim) ? c.batch_shape[l] : 1;
         a.grid[l] = (l < c.dim) ? h->grid[l] : 1;
+        a.image_shape[l] = (l < c.dim) ? c.image_shape[l] : 1;
     }
+    a.overlap = c.overlap;
     a.Nb = h->Nb; a.K = c.kernels; a.KW = h->KW;
     a.kc = h->kc;
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
@@ -378,6 +380,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         Nb *= cfg->batch_shape[l];
         NB *= cfg->image_shape[l] / cfg->batch_shape[l];
     }
+    if (cfg->overlap < 0 || cfg->overlap > 64) return fail(SMOE_ERR_INVALID, "smoe_shared_create: overlap must be 0..64");
     if (!smoe::shared_supported(cfg->dim, cfg->channels, (int)Nb))
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: batch too large (<= 2048 pixels for 1 channel, <= 1024 for 3)");
     const int KW = (cfg->kernels + 31) / 32;
@@ -409,11 +412,22 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     }
     std::vector<float> probes((size_t)NB * D * 3);
     for (long b = 0; b < NB; ++b) {
+        // min / max / mid of the batch's window per axis (smoe.py:2322-2331).  With a halo the window is
+        // cut from the zero-padded joint domain (smoe.py:21,28): a window that leaves the image on ANY
+        // axis contains all-zero pixels, which pulls the minimum of every coordinate to 0
         long rem = b;
+        int org[SMOE_MAX_DIM] = {0, 0, 0};
+        bool leaves_image = false;
         for (int l = D - 1; l >= 0; --l) {
-            const int o = (int)(rem % h->grid[l]) * cfg->batch_shape[l];
+            org[l] = (int)(rem % h->grid[l]) * cfg->batch_shape[l];
             rem /= h->grid[l];
-            const double mn = axd[l][o], mx = axd[l][o + cfg->batch_shape[l] - 1];
+            leaves_image = leaves_image || (org[l] - cfg->overlap < 0) ||
+                           (org[l] + cfg->batch_shape[l] + cfg->overlap > cfg->image_shape[l]);
+        }
+        for (int l = 0; l < D; ++l) {
+            const int lo = std::max(0, org[l] - cfg->overlap);
+            const int hi = std::min(cfg->image_shape[l], org[l] + cfg->batch_shape[l] + cfg->overlap) - 1;
+            const double mn = leaves_image ? 0.0 : axd[l][lo], mx = axd[l][hi];
             probes[((size_t)b * D + l) * 3 + 0] = (float)mn;
             probes[((size_t)b * D + l) * 3 + 1] = (float)mx;
             probes[((size_t)b * D + l) * 3 + 2] = (float)((mn + mx) / 2.0);

@@ -101,6 +101,8 @@ struct SharedArgs {
     int axis_off[SMOE_MAX_DIM];
     int batch_shape[SMOE_MAX_DIM];
     int grid[SMOE_MAX_DIM];   // batches per axis
+    int image_shape[SMOE_MAX_DIM];
+    int overlap;              // halo width (pixels per side) used by the influence test only
     uint32_t* lists;          // [nb][KW] kernel-list bitmaps
     int b0, NB, Nb, K, KW;    // NB = batches in this launch
     float* loss;              // [nb] or null

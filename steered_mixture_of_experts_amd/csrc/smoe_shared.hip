@@ -232,6 +232,71 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         }
     }
 
+    // ---- 3b. halo (overlap_of_batches > 0): the window's extra pixels take part in the influence test
+    // only (smoe.py:829 runs on the whole window, the loss is cropped, smoe.py:909-923); a window pixel
+    // outside the image has all-zero coordinates (np.pad of the joint domain, smoe.py:21,28)
+    if (a.overlap > 0) {
+        int ext[D], next = 1;
+#pragma unroll
+        for (int l = 0; l < D; ++l) { ext[l] = a.batch_shape[l] + 2 * a.overlap; next *= ext[l]; }
+        for (int e = tid; e < next; e += SH_THREADS) {
+            int rem = e;
+            bool interior = true, inside_img = true;
+            float xh[D];
+            int gi[D];
+#pragma unroll
+            for (int l = D - 1; l >= 0; --l) {
+                const int el = rem % ext[l];
+                rem /= ext[l];
+                interior = interior && (el >= a.overlap) && (el < a.overlap + a.batch_shape[l]);
+                gi[l] = bo[l] + el - a.overlap;
+                inside_img = inside_img && (gi[l] >= 0) && (gi[l] < a.image_shape[l]);
+            }
+            if (interior) continue;
+#pragma unroll
+            for (int l = 0; l < D; ++l) xh[l] = inside_img ? a.axis_coords[a.axis_off[l] + gi[l]] : 0.0f;
+            // normaliser and influence for this pixel, reading the kernel records straight from global
+            // memory (halo pixels are few; the LDS chunk may hold another part of the list)
+            float Sh = 0.0f;
+            for (int i = 0; i < Kact; ++i) {
+                const int k = s_list[i];
+                float maha = 0.0f, det = 1.0f;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    float zz = 0.0f;
+#pragma unroll
+                    for (int l = m; l < D; ++l) {
+                        const float Alm = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m];
+                        if (l == m) det *= Alm;
+                        zz = fmaf(xh[l] - a.p.musX[(size_t)k * D + l], SQ * Alm, zz);
+                    }
+                    maha = fmaf(zz, zz, maha);
+                }
+                const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
+                Sh += nq * a.p.pis[k] * fexp2(-maha);
+            }
+            const float invh = frcp(fmaxf(Sh, 10e-12f));
+            for (int i = 0; i < Kact; ++i) {
+                const int k = s_list[i];
+                float maha = 0.0f, det = 1.0f;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    float zz = 0.0f;
+#pragma unroll
+                    for (int l = m; l < D; ++l) {
+                        const float Alm = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m];
+                        if (l == m) det *= Alm;
+                        zz = fmaf(xh[l] - a.p.musX[(size_t)k * D + l], SQ * Alm, zz);
+                    }
+                    maha = fmaf(zz, zz, maha);
+                }
+                const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
+                if (nq * a.p.pis[k] * fexp2(-maha) * invh > a.kc.tau) s_flag[i] = 1;
+            }
+        }
+        __syncthreads();
+    }
+
     // ---- 4. clip + fake quant, loss, dL/dy (smoe.py:857,899,905-937) ----------------------------------
     float Gc[PXL][C], dot[PXL];
     float loss_part = 0.0f, sse_part = 0.0f;

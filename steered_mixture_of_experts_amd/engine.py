@@ -258,6 +258,7 @@ class SharedConfig:
     u_l1: float = 0.0
     start_pis: int = 0
     only_y_gamma: bool = False
+    overlap: int = 0
 
     @property
     def dim(self) -> int:
@@ -287,6 +288,7 @@ class SharedEngine:
         c.grad_clip, c.pis_l1, c.u_l1 = cfg.grad_clip or 0.0, cfg.pis_l1, cfg.u_l1
         c.start_pis = cfg.start_pis or cfg.kernels
         c.only_y_gamma = int(cfg.only_y_gamma)
+        c.overlap = int(cfg.overlap)
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_shared_create(C.byref(self._h), C.byref(c)))
         self.num_batches = int(self.lib.smoe_shared_num_batches(self._h))

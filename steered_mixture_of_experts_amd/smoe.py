@@ -532,7 +532,8 @@ class SharedSmoe:
     accumulated and one Adam step follows (smoe.py:1148-1150,1788).  ``get_params()`` returns the
     reference's layout exactly (leading axis = kernels).  Multi-GPU: the BATCHES are sharded over
     ranks and the accumulated gradient buffer is all-reduced (RCCL) before the Adam step.
-    ``overlap_of_batches`` must be 0."""
+    ``overlap_of_batches`` > 0: the halo of every batch takes part in the kernel-list influence test
+    only (its loss is cropped, smoe.py:909-923)."""
 
     def __init__(self, image, kernels_per_dim=None, train_pis=True, init_params=None, start_batches=1,
                  batch_size=None, train_gammas=True, train_musx=True, use_determinant=False, normalize_pis=True,
@@ -541,8 +542,6 @@ class SharedSmoe:
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
-        if overlap_of_batches:
-            raise NotImplementedError("overlapping batches are not built (SURVEY 8(f-1) halo)")
         assert kernels_per_dim is not None or init_params is not None, \
             "You need to specify the kernel grid size or give initial parameters."
         image = np.asarray(image, dtype=np.float32)
@@ -556,7 +555,7 @@ class SharedSmoe:
         self.quantization_mode, self.quantize_pis = 0, False
         self.bit_depths = self.lower_bounds = self.upper_bounds = None
         self.only_y_gamma = self.ssim_opt = self.use_diff_center = self.radial_as = False
-        self.overlap = 0
+        self.overlap = int(overlap_of_batches)                            # smoe.py:244
         if batch_size is None or batch_size[0] is None:
             bs = blk.get_batch_shape(start_batches, tuple(image.shape[:d]) + (d + image.shape[-1],))[:-1]
         elif len(batch_size) == d:
@@ -568,7 +567,8 @@ class SharedSmoe:
         for ii in range(d):                                               # smoe.py:239-241
             if image.shape[ii] % bs[ii] > 0:
                 raise ValueError("Required BatchSize is not compatible to input dimensions")
-        self.batch_size_valued = self.batch_size = bs
+        self.batch_size_valued = bs
+        self.batch_size = tuple(int(b) + 2 * self.overlap for b in bs)    # smoe.py:245
         self.Nb = int(np.prod(bs))
         blocks_all, _ = blk.image_to_blocks(image, bs)
         self.num_batches = self.start_batches = blocks_all.shape[0]
@@ -614,7 +614,7 @@ class SharedSmoe:
             lr_expert=o1._lr if o1 else 0.0, lr_pis=o2._lr if o2 else 0.0, lr_steer=o3._lr if o3 else 0.0,
             beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999, adam_eps=o1._epsilon if o1 else 1e-8,
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
-            start_pis=self.kernels)
+            start_pis=self.kernels, overlap=self.overlap)
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:

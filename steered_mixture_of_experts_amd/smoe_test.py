@@ -8,7 +8,8 @@ three Adam optimizers with ``base_lr``, ``base_lr/lr_div``, ``base_lr*lr_mult``
 ``--mode blocks`` (default): every ``-bz`` block is an independent model with ``-k`` kernels per axis
 (the per-block hot path).  ``--mode shared``: the reference's whole-image fit -- ``-k`` is the GLOBAL
 kernel grid and ``-bz`` the pixel batch of a pass.  Flags of features that are not built (kernel
-adding, support vectors, motion models, SSIM, fake-quant training, batch overlap, sampling) are
+adding, support vectors, motion models, SSIM, fake-quant training, sampling; batch overlap outside
+``--mode shared``) are
 accepted for command-line compatibility but must keep their inactive values.
 """
 import argparse
@@ -91,13 +92,15 @@ def main(args):
     if len(args.bit_depths) != 5:
         raise ValueError("Number of bit depths must be five!")                        # smoe_test.py:24-25
     inactive = {"inc_steps": 0, "radial_as": False, "ssim_opt": False, "sampling_percentage": 100,
-                "overlap_of_batches": 0, "svreg": 0, "hpc_mode": False, "kernel_count_norm_l1": False,
+                "svreg": 0, "hpc_mode": False, "kernel_count_norm_l1": False,
                 "train_svs": False, "train_trafo": False, "train_inverse_cov": False,
                 "only_rec_from_checkpoint": False, "checkpoint_path": None}
     for name, val in inactive.items():
         if getattr(args, name) != val:
             raise NotImplementedError(f"--{name}={getattr(args, name)!r}: this feature is outside the per-block hot path "
                                       "(SURVEY section 8) and is not built")
+    if args.overlap_of_batches and args.mode != 'shared':
+        raise NotImplementedError("--overlap_of_batches needs --mode shared (independent blocks have no neighbours)")
     if args.quantization_mode >= 2:
         raise NotImplementedError("fake-quantisation training (modes 2/3) is not built; mode 1 is")
     orig, precision, _ = read_image(args.image_path, args.use_yuv)                    # smoe_test.py:39
@@ -124,7 +127,7 @@ def main(args):
     else:
         if args.use_diff_center or only_y_gamma or args.quantization_mode or loss_mask is not None:
             raise NotImplementedError("--mode shared supports the plain model only")
-        smoe = SharedSmoe(orig, kpd, **common)
+        smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, **common)
     optimizer1 = Adam(args.base_lr)                                                   # smoe_test.py:84-86
     optimizer2 = Adam(args.base_lr / args.lr_div)
     optimizer3 = Adam(args.base_lr * args.lr_mult)

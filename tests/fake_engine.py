@@ -132,6 +132,8 @@ class OracleSharedEngine:
             lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2, adam_eps=cfg.adam_eps,
             grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1, start_pis=cfg.start_pis or cfg.kernels)
         self.coords = o.global_batch_coords(cfg.image_shape, cfg.batch_shape)
+        ov = int(getattr(cfg, "overlap", 0))
+        self.halo = o.global_halo_coords(cfg.image_shape, cfg.batch_shape, ov) if ov > 0 else None
         self.num_batches = self.coords.shape[0]
         self.list_words = (cfg.kernels + 31) // 32
         self.batch_pixels = self.coords.shape[1]
@@ -166,10 +168,14 @@ class OracleSharedEngine:
     def _p(self, params):
         return {k: params[k].numpy()[None] for k in NAMES}
 
+    def _halo(self, first_batch, nb):
+        return None if self.halo is None else self.halo[first_batch:first_batch + nb]
+
     def forward(self, target, params, lists, first_batch=0, want_recon=True, want_argmax=False, update_lists=True):
         nb = lists.shape[0]
         tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
-        f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg)
+        f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg,
+                          halo_coords=self._halo(first_batch, nb))
         if update_lists:
             self._setbits(lists, f["lists_new"])
         return {"loss": torch.from_numpy(f["loss"].astype(np.float32)), "sse": torch.from_numpy(f["sse"].astype(np.float32)),
@@ -190,7 +196,7 @@ class OracleSharedEngine:
         nb = lists.shape[0]
         tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
         f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg,
-                          np.float32, want_grads=True)
+                          np.float32, want_grads=True, halo_coords=self._halo(first_batch, nb))
         self._setbits(lists, f["lists_new"])
         buf = self.grad_buffer()
         flat = np.concatenate([f["grads"][k][0].astype(np.float64).ravel() for k in NAMES])
@@ -225,5 +231,6 @@ class OracleSharedEngine:
 
     def update_kernel_list(self, params, lists, first_batch=0):
         nb = lists.shape[0]
-        new = o.shared_readmit(self._p(params), self._mask(lists), self.coords[first_batch:first_batch + nb], self.ocfg)
+        win = self.coords if self.halo is None else self.halo
+        new = o.shared_readmit(self._p(params), self._mask(lists), win[first_batch:first_batch + nb], self.ocfg)
         self._setbits(lists, new)

@@ -203,8 +203,34 @@ def test_shared_kernel_facade_matches_the_numpy_restatement():
     assert np.array_equal(np.array(s.kernel_list_per_batch), info["lists"])
     with pytest.raises(ValueError):
         SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[10, 16], engine_factory=OracleSharedEngine)
-    with pytest.raises(NotImplementedError):
-        SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[16, 16], overlap_of_batches=2, engine_factory=OracleSharedEngine)
+
+
+def test_shared_facade_with_overlapping_batches():
+    """overlap_of_batches: the halo only feeds the kernel-list influence test and the readmission probes
+    (smoe.py:909-923,2322-2331); the facade follows oracle.shared_fit with the extended windows."""
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(64, 48, seed=4)
+    s = SharedSmoe(img, kernels_per_dim=[8, 6], batch_size=[16, 16], use_determinant=True, overlap_of_batches=3,
+                   engine_factory=OracleSharedEngine)
+    assert s.batch_size == (22, 22) and s.batch_size_valued == (16, 16) and s.overlap == 3        # smoe.py:244-245
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(6, val_iter=3, ukl_iter=2)
+    p0 = o.shared_init_params(img, [8, 6])
+    coords = o.global_batch_coords((64, 48), (16, 16))
+    halo = o.global_halo_coords((64, 48), (16, 16), 3)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=48, lr_steer=0.01)
+    pn, st, info = o.shared_fit(p0, tb.reshape(12, -1, 1), coords, cfg, 6, val_iter=3, ukl_iter=2, dtype=np.float32,
+                                halo_coords=halo)
+    _, _, plain = o.shared_fit(p0, tb.reshape(12, -1, 1), coords, cfg, 6, val_iter=3, ukl_iter=2, dtype=np.float32)
+    got = s.get_params()
+    for k in got:       # the engine double sums the batch gradients in fp64, shared_fit in fp32; where |g| ~ eps
+        # Adam amplifies that rounding to a fraction of lr per step (A_corr starts at a zero gradient)
+        assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
+    assert np.array_equal(np.array(s.kernel_list_per_batch), info["lists"])
+    assert info["lists"].sum() > plain["lists"].sum()              # the halo keeps neighbouring kernels listed
+    assert s.get_reconstruction().shape == img.shape
 
 
 def test_start_batches_selects_the_block_shape():

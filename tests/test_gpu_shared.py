@@ -215,3 +215,62 @@ def test_shared_facade_on_gpu_matches_the_oracle_backed_facade():
     assert abs(g.get_psnr() - c.get_psnr()) < 0.2
     assert g.get_losses()[-1][1] < g.get_losses()[0][1]
     assert g.get_weight_matrix_argmax().shape == (64, 96)
+
+
+@pytest.mark.parametrize("shape,bshape,C,kpd,ov", [((48, 40), (16, 8), 1, [12, 12], 3),
+                                                   ((64, 64), (32, 32), 3, [8, 8], 4),
+                                                   ((32, 32, 8), (16, 16, 4), 1, [4, 4, 3], 2)])
+def test_shared_overlap_halo(shape, bshape, C, kpd, ov):
+    """overlap_of_batches > 0 (smoe.py:244-245): loss, reconstruction and gradients are those of the
+    interior (smoe.py:909-923); the halo -- cut from the zero-padded domain (smoe.py:21,28) -- joins the
+    influence test that prunes the kernel lists (smoe.py:829,1763-1766) and sets the readmission probes
+    (smoe.py:2322-2331)."""
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, C == 3, perturb=True)
+    halo = o.global_halo_coords(shape, bshape, ov)
+    lists = np.ones((NB, K), bool)
+    ref = o.shared_pass(p, tgt, coords, lists, cfg, np.float32, halo_coords=halo)
+    plain = o.shared_pass(p, tgt, coords, lists, cfg, np.float32)
+    fe64 = o.forward(o._bcast(p, NB), np.zeros(halo.shape[:2] + (C,)), halo.astype(np.float64), lists, cfg, None, np.float64)
+    near_tau = (np.abs(fe64["w"] - 0.5 / 256) < 1e-6).any(axis=2)
+    assert ref["lists_new"].sum() > plain["lists_new"].sum()       # the halo really keeps more kernels listed
+    eng = _engine(shape, bshape, C, K, C == 3, overlap=ov)
+    eng0 = _engine(shape, bshape, C, K, C == 3)
+    dp = _dev(p)
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    dl, dl0 = eng.new_lists(), eng0.new_lists()
+    out = eng.forward(T, dp, dl, want_recon=True)
+    out0 = eng0.forward(T, dp, dl0, want_recon=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out["recon"], out0["recon"]) and torch.equal(out["loss"], out0["loss"])
+    new = _mask(dl.cpu().numpy().view(np.uint32), K)
+    assert (new == ref["lists_new"])[~near_tau].all()
+    assert (new != _mask(dl0.cpu().numpy().view(np.uint32), K)).any()
+    # accumulated gradients do not see the halo
+    l1, l0 = eng.new_lists(), eng0.new_lists()
+    eng.accumulate(T, dp, l1)
+    eng0.accumulate(T, dp, l0)
+    torch.cuda.synchronize()
+    ga, gb = eng.grad_buffer(), eng0.grad_buffer()                 # fp64 atomics: order differs between launches
+    assert float((ga - gb).abs().max()) <= 1e-10 * float(gb.abs().max())
+    eng.grad_buffer().zero_()
+    eng0.grad_buffer().zero_()
+    # readmission probes: min / max / mid of the padded window
+    empty = torch.zeros_like(dl)
+    eng.update_kernel_list(dp, empty)
+    want = o.shared_readmit(p, np.zeros((NB, K), bool), halo, cfg, np.float32)
+    assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want)
+    # a short fit follows the oracle's lists
+    cfg2 = o.OracleConfig(block_shape=bshape, channels=C, kernels=K, use_yuv=(C == 3), lr_steer=0.01)
+    eng2 = _engine(shape, bshape, C, K, C == 3, overlap=ov, lr_steer=0.01)
+    pn, _, info = o.shared_fit(p, tgt, coords, cfg2, 4, val_iter=4, ukl_iter=2, dtype=np.float32, halo_coords=halo)
+    dp2, dl2 = _dev(p), eng2.new_lists()
+    st2 = eng2.new_adam_state(dp2)
+    eng2.forward(T, dp2, dl2, want_recon=False)
+    for _ in range(2):
+        eng2.fit(T, dp2, st2, dl2, 2)
+        eng2.update_kernel_list(dp2, dl2)
+    eng2.forward(T, dp2, dl2, want_recon=False)
+    torch.cuda.synchronize()
+    assert (_mask(dl2.cpu().numpy().view(np.uint32), K) == info["lists"]).mean() > 0.98
+    for e in (eng, eng0, eng2):
+        e.close()
