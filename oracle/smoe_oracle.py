@@ -68,6 +68,7 @@ class OracleConfig:
     u_l1: float = 0.0                     # smoe.py:1044
     start_pis: Optional[int] = None       # smoe.py:264 (K0 of the l1 normaliser)
     only_y_gamma: bool = False            # smoe.py:725-729 (slopes only for channel 0)
+    ssim_opt: bool = False                # smoe.py:929,980-1011: loss_pixel = 1 - SSIM (2-d blocks)
 
     @property
     def dim(self) -> int:
@@ -191,6 +192,80 @@ def fake_quant01(y, precision, T):
     return np.floor(cl * inv_scale + T(0.5)) * scale
 
 
+# --------------------------------------------------------------------------
+# SSIM loss (smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d blocks
+# --------------------------------------------------------------------------
+SSIM_SIZE, SSIM_SIGMA, SSIM_PAD = 11, 1.5, 5                  # image_ops_impl.py:180-181; smoe.py:994
+SSIM_C1, SSIM_C2 = 0.01 ** 2, 0.03 ** 2                       # image_ops_impl.py:74-75,110-111 (max_val = 1)
+
+
+def ssim_window(T=np.float32):
+    """_fspecial_gauss (image_ops_impl.py:132-149): softmax over the 11x11 grid of
+    -0.5 (r^2 + c^2) / sigma^2."""
+    c = np.arange(SSIM_SIZE, dtype=T) - T(SSIM_SIZE - 1) / T(2)
+    g = np.square(c) * T(-0.5 / SSIM_SIGMA ** 2)
+    g2 = g[None, :] + g[:, None]
+    e = np.exp(g2 - g2.max())
+    return (e / e.sum()).astype(T)
+
+
+def _ssim_reduce(img, win):
+    """reducer (image_ops_impl.py:203-219): VALID depthwise correlation of (B,H,W) with the window."""
+    v = np.lib.stride_tricks.sliding_window_view(img, (SSIM_SIZE, SSIM_SIZE), axis=(1, 2))
+    return np.einsum("bijuv,uv->bij", v, win)
+
+
+def ssim_and_grad(q, t, block_shape, T=np.float32, want_grad=False):
+    """custom_ssim on SYMMETRIC-padded blocks (smoe.py:993-998): q, t (B,N,C) -> ssim (B,C) per channel
+    = mean over the bh x bw window positions of luminance * contrast-structure
+    (image_ops_impl.py:110-129,228-230), and d ssim_c / d q (B,N,C) when asked."""
+    B, N, C = q.shape
+    bh, bw = (int(v) for v in block_shape)
+    assert bh >= SSIM_PAD and bw >= SSIM_PAD, "SYMMETRIC padding by 5 needs blocks of at least 5 pixels per axis"
+    win = ssim_window(T)
+    c1, c2 = T(SSIM_C1), T(SSIM_C2)
+    pad = ((0, 0), (SSIM_PAD, SSIM_PAD), (SSIM_PAD, SSIM_PAD))
+    ssim = np.empty((B, C), dtype=T)
+    grad = np.zeros((B, N, C), dtype=T) if want_grad else None
+    # index of the block pixel every padded position mirrors
+    ridx = np.pad(np.arange(bh), SSIM_PAD, mode="symmetric")
+    cidx = np.pad(np.arange(bw), SSIM_PAD, mode="symmetric")
+    flat = (ridx[:, None] * bw + cidx[None, :]).ravel()
+    for c in range(C):
+        x = np.pad(q[:, :, c].reshape(B, bh, bw).astype(T), pad, mode="symmetric")
+        y = np.pad(t[:, :, c].reshape(B, bh, bw).astype(T), pad, mode="symmetric")
+        mx, my = _ssim_reduce(x, win), _ssim_reduce(y, win)
+        num0 = mx * my * T(2)
+        den0 = np.square(mx) + np.square(my)
+        lum = (num0 + c1) / (den0 + c1)
+        num1 = _ssim_reduce(x * y, win) * T(2)
+        den1 = _ssim_reduce(np.square(x) + np.square(y), win)
+        cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+        ssim[:, c] = np.mean(lum * cs, axis=(1, 2))
+        if not want_grad:
+            continue
+        # per window position: d(lum*cs)/d mu_x, /d E[x^2], /d E[xy]
+        D0, D1 = den0 + c1, den1 - den0 + c2
+        N0, N1 = num0 + c1, num1 - num0 + c2
+        d_mx = cs * (T(2) * my * D0 - N0 * T(2) * mx) / np.square(D0) + \
+            lum * (-T(2) * my * D1 + N1 * T(2) * mx) / np.square(D1)
+        d_s = -lum * N1 / np.square(D1)
+        d_p = lum * T(2) / D1
+        # adjoint of the VALID correlation: full correlation of the zero-embedded coefficient maps
+        full = ((0, 0), (SSIM_SIZE - 1, SSIM_SIZE - 1), (SSIM_SIZE - 1, SSIM_SIZE - 1))
+        wf = win[::-1, ::-1]
+        ga = _ssim_reduce(np.pad(d_mx, full), wf)
+        gb = _ssim_reduce(np.pad(d_s, full), wf)
+        gc = _ssim_reduce(np.pad(d_p, full), wf)
+        gpad = (ga + T(2) * x * gb + y * gc) / T(bh * bw)            # (B, bh+10, bw+10)
+        gp = gpad.reshape(B, -1)
+        gc_flat = np.zeros((B, N), dtype=T)
+        for bi in range(B):
+            np.add.at(gc_flat[bi], flat, gp[bi])                     # fold the mirrored positions back
+        grad[:, :, c] = gc_flat
+    return ssim, grad
+
+
 def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
             active: np.ndarray, cfg: OracleConfig, loss_w: Optional[np.ndarray] = None,
             dtype=np.float32, want_grads: bool = False, q_override: Optional[np.ndarray] = None):
@@ -277,6 +352,10 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     else:                                                    # smoe.py:937
         cw = np.full((C,), 1.0 / (N * C), dtype=T)
     loss_pixel = np.sum(np.sum(lp, axis=1) * cw[None, :], axis=1)
+    if cfg.ssim_opt:                                         # smoe.py:929,1006-1010 (loss_weights unused there)
+        sw = (np.array([6, 1, 1], dtype=T)[:C] / T(8)) if cfg.use_yuv else np.full((C,), 1.0 / C, dtype=T)
+        ssim_c, dssim = ssim_and_grad(q, t, cfg.block_shape, T, want_grad=want_grads)
+        loss_pixel = T(1) - np.sum(ssim_c * sw[None, :], axis=1)
     diagA = np.diagonal(A, axis1=-2, axis2=-1)               # (B,K,d)
     reg_pi = T(cfg.pis_l1) * np.sum(np.where(act, pis, T(0)), axis=1) / T(cfg.k0)     # smoe.py:1027
     reg_u = T(cfg.u_l1) * np.sum(np.where(act[:, :, None], diagA, T(0)), axis=(1, 2))  # smoe.py:1044
@@ -292,6 +371,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     nudged_max = T(2 ** cfg.precision - 1) * (T(1) / T(2 ** cfg.precision - 1))
     inside = np.logical_and(y >= T(0), y <= np.minimum(T(1), nudged_max))   # clip + fake-quant STE
     G = (cw[None, None, :] * T(2) * a * np.sign(diff) * lw[:, :, None]) * inside   # (B,N,C)
+    if cfg.ssim_opt:
+        G = (-sw[None, None, :] * dssim) * inside
     # experts
     g_nu = np.einsum("bkn,bnc->bkc", wt, G)
     g_gam = np.einsum("bkn,bnl,bnc->bklc", wt, x, G)

@@ -29,9 +29,42 @@ class _FakeQuant01(torch.autograd.Function):
         return g * inside.to(g.dtype), None
 
 
+def custom_ssim_2d(img1, img2):
+    """ops/image_ops_impl.py:77-233 for (H,W,C) inputs with max_val = 1: 11x11 Gaussian (sigma 1.5, built with
+    a softmax), VALID depthwise correlation, mean of luminance * contrast-structure per channel."""
+    dt = img1.dtype
+    c = torch.arange(11, dtype=dt) - 5.0
+    g = (c ** 2) * (-0.5 / 1.5 ** 2)
+    g = (g.reshape(1, -1) + g.reshape(-1, 1)).reshape(1, -1)
+    kernel = torch.softmax(g, dim=1).reshape(1, 1, 11, 11)
+    C = img1.shape[-1]
+    kern = kernel.repeat(C, 1, 1, 1)
+
+    def reducer(x):
+        return torch.nn.functional.conv2d(x.permute(2, 0, 1).unsqueeze(0), kern, groups=C)[0].permute(1, 2, 0)
+
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    mean0, mean1 = reducer(img1), reducer(img2)
+    num0 = mean0 * mean1 * 2.0
+    den0 = mean0 ** 2 + mean1 ** 2
+    luminance = (num0 + c1) / (den0 + c1)
+    num1 = reducer(img1 * img2) * 2.0
+    den1 = reducer(img1 ** 2 + img2 ** 2)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return torch.mean(luminance * cs, dim=(0, 1))
+
+
+def _symmetric_pad(img, pad):
+    """tf.pad(..., "SYMMETRIC") on the two leading axes of (H,W,C)."""
+    import numpy as np
+    ri = torch.from_numpy(np.pad(np.arange(img.shape[0]), pad, mode="symmetric"))
+    ci = torch.from_numpy(np.pad(np.arange(img.shape[1]), pad, mode="symmetric"))
+    return img[ri][:, ci]
+
+
 def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0.5,
                    use_determinant=True, use_yuv=False, train_gammas=True,
-                   pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None):
+                   pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None):
     """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
     with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
     Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
@@ -84,6 +117,16 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
         loss_pixel = 6 / 8 * lp[:, 0].mean() + 1 / 8 * lp[:, 1:].mean(dim=0).sum()
     else:
         loss_pixel = lp.mean()
+    if ssim_opt:                                                                 # smoe.py:980-1011
+        bh, bw = block_shape
+        r2 = _symmetric_pad(res.reshape(bh, bw, C), 5)
+        t2 = _symmetric_pad(target.reshape(bh, bw, C), 5)
+        ssim_per_channel = custom_ssim_2d(r2, t2)
+        if use_yuv:
+            ssim = torch.sum(ssim_per_channel * torch.tensor([6.0, 1.0, 1.0], dtype=dt)) / 8
+        else:
+            ssim = torch.mean(ssim_per_channel)
+        loss_pixel = 1 - ssim
     k0 = K if start_pis is None else start_pis
     loss = loss_pixel + pis_l1 * pis.sum() / k0 + u_l1 * torch.diagonal(A, dim1=-2, dim2=-1).sum()
     return {"loss": loss, "mse_op": mse * (2 ** precision) ** 2, "res": res, "pre": pre,
