@@ -36,6 +36,8 @@ def load():
 
 def _cfg(cfg):
     """cfg: oracle.smoe_oracle.OracleConfig"""
+    if getattr(cfg, "ssim_opt", False):
+        raise NotImplementedError("the plain-C restatement covers the margin loss only; SSIM lives in smoe_oracle.py")
     c = OracleCfg()
     c.dim, c.channels, c.kernels, c.pixels = cfg.dim, cfg.channels, cfg.kernels, cfg.pixels
     c.precision, c.margin = cfg.precision, cfg.margin

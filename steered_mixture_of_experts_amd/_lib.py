@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmoe_hip.so")
 
-SMOE_ABI_VERSION = 1
+SMOE_ABI_VERSION = 2
 SMOE_OK = 0
 SMOE_ERR_INVALID = -1
 SMOE_ERR_UNSUPPORTED = -2
@@ -38,7 +38,7 @@ class SmoeConfig(C.Structure):
         ("train_musx", C.c_int32), ("lr_expert", C.c_float), ("lr_pis", C.c_float),
         ("lr_steer", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
         ("adam_eps", C.c_float), ("grad_clip", C.c_float), ("pis_l1", C.c_float),
-        ("u_l1", C.c_float), ("start_pis", C.c_int32), ("only_y_gamma", C.c_int32),
+        ("u_l1", C.c_float), ("start_pis", C.c_int32), ("only_y_gamma", C.c_int32), ("ssim_opt", C.c_int32),
     ]
 
 

@@ -17,6 +17,7 @@ struct smoe_context {
     int N;
     float* d_coords;     // [D][N]
     float* d_probes;     // [D][3]
+    float* d_ssim_T;     // ssim_opt: tap tables Tr [bh][bh], Tc [bw][bw]
     int force_g;
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
@@ -56,6 +57,23 @@ bool params_ok(const smoe_params* p) {
     return p && p->pis && p->musX && p->A_diagonal && p->A_corr && p->gamma_e && p->nu_e;
 }
 
+// ssim_opt: per axis the b x b matrix of "SYMMETRIC pad by 5, correlate with the 11-tap Gaussian, VALID"
+// (smoe.py:993-996; image_ops_impl.py:132-149: softmax of -0.5 (a-5)^2 / 1.5^2, separable):
+// T[i][j] = sum_a g[a] [mirror(i + a - 5) == j]
+void ssim_axis_table(int b, float* out) {
+    double g[11], sum = 0.0;
+    for (int a = 0; a < 11; ++a) { g[a] = std::exp(-0.5 * (a - 5) * (a - 5) / (1.5 * 1.5)); sum += g[a]; }
+    std::vector<double> T((size_t)b * b, 0.0);
+    for (int i = 0; i < b; ++i)
+        for (int a = 0; a < 11; ++a) {
+            int r = i + a - 5;
+            if (r < 0) r = -1 - r;                 // SYMMETRIC: the edge sample is repeated
+            if (r >= b) r = 2 * b - 1 - r;
+            T[(size_t)i * b + r] += g[a] / sum;
+        }
+    for (size_t i = 0; i < T.size(); ++i) out[i] = (float)T[i];
+}
+
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
@@ -65,9 +83,15 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
     // Large blocks (>= 1024 pixels) always use a whole wavefront per block: 16 lanes would leave 64+
     // pixels per lane, and with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
     int want = h->force_g ? h->force_g : ((num_blocks >= 8192 && h->N <= 512) ? 16 : 64);
+    if (h->cfg.ssim_opt) want = 64;                  // the SSIM stage works on one block per wavefront
     const smoe::Variant* fallback = nullptr;
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels) continue;
+        if (h->cfg.ssim_opt) {
+            if (v[i].G != 64) continue;
+            if (v[i].lds_bytes_ssim(h->N, has_lw, h->cfg.block_shape[0], h->cfg.block_shape[1]) > 160u * 1024u) continue;
+            return &v[i];
+        }
         if (v[i].lds_bytes(h->N, has_lw) > 160u * 1024u) continue;
         if (v[i].G == want) return &v[i];
         if (!fallback) fallback = &v[i];
@@ -104,6 +128,13 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         N *= cfg->block_shape[l];
     }
     if (N > 8192) return fail(SMOE_ERR_INVALID, "smoe_create: more than 8192 pixels per block");
+    if (cfg->ssim_opt) {
+        // the reference pads every axis SYMMETRIC by 5 (smoe.py:993-1003), which TF only accepts for axes of
+        // at least 5 samples; 3-d blocks would need an 11^3 window over a padded time axis and are not built
+        if (cfg->dim != 2) return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt is built for 2-d blocks only");
+        if (cfg->block_shape[0] < 5 || cfg->block_shape[1] < 5)
+            return fail(SMOE_ERR_INVALID, "smoe_create: ssim_opt needs at least 5 pixels per block axis (SYMMETRIC padding by 5)");
+    }
     if (!smoe_is_supported(cfg->dim, cfg->channels, cfg->kernels)) {
         char buf[160];
         snprintf(buf, sizeof buf, "smoe_create: no kernel instantiated for (dim=%d, channels=%d, kernels=%d)",
@@ -123,6 +154,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->force_g = 0;
     h->d_coords = nullptr;
     h->d_probes = nullptr;
+    h->d_ssim_T = nullptr;
     const int D = cfg->dim;
 
     // per-pixel coordinates [D][N], 'ij' meshgrid flattened row-major (smoe.py:2418-2421,1650)
@@ -149,9 +181,18 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_probes, sizeof(float) * D * 3);
     if (e == hipSuccess) e = hipMemcpy(h->d_coords, h->h_coords.data(), sizeof(float) * D * N, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * D * 3, hipMemcpyHostToDevice);
+    if (e == hipSuccess && cfg->ssim_opt) {
+        const int bh = cfg->block_shape[0], bw = cfg->block_shape[1];
+        std::vector<float> tabs((size_t)bh * bh + (size_t)bw * bw);
+        ssim_axis_table(bh, tabs.data());
+        ssim_axis_table(bw, tabs.data() + (size_t)bh * bh);
+        e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
+        if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (h->d_coords) (void)hipFree(h->d_coords);
         if (h->d_probes) (void)hipFree(h->d_probes);
+        if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
         delete h;
         return fail_hip(e, "smoe_create: workspace");
     }
@@ -175,6 +216,15 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     kc.use_det = cfg->use_determinant ? 1 : 0;
     kc.train_gammas = cfg->train_gammas ? 1 : 0;
     kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;   // smoe.py:725
+    for (int c = 0; c < SMOE_MAX_CHANNELS; ++c) kc.sw[c] = 0.0f;
+    for (int c = 0; c < C; ++c) {                       // smoe.py:1006-1009, mean over the bh*bw window positions
+        const double w = cfg->use_yuv ? ((c == 0) ? 6.0 / 8.0 : 1.0 / 8.0) : 1.0 / (double)C;
+        kc.sw[c] = (float)(w / (double)N);
+    }
+    if (cfg->ssim_opt && !find_variant(h, 1, false)) {
+        smoe_destroy(h);
+        return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt planes of this block size do not fit in LDS");
+    }
     *out = h;
     return SMOE_OK;
 }
@@ -184,6 +234,7 @@ int smoe_destroy(smoe_handle h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->d_coords) (void)hipFree(h->d_coords);
     if (h->d_probes) (void)hipFree(h->d_probes);
+    if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
     delete h;
     return SMOE_OK;
 }
@@ -234,7 +285,9 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.reg_pi = h->cfg.pis_l1 / (float)(h->cfg.start_pis > 0 ? h->cfg.start_pis : h->cfg.kernels);
     a.reg_u = h->cfg.u_l1;
     a.kc = h->kc;
-    HIP_TRY(v->fwd(a, (hipStream_t)stream), "smoe_forward launch");
+    a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1];
+    if (h->cfg.ssim_opt) HIP_TRY(v->fwd_ssim(a, (hipStream_t)stream), "smoe_forward (ssim) launch");
+    else HIP_TRY(v->fwd(a, (hipStream_t)stream), "smoe_forward launch");
     return SMOE_OK;
 }
 
@@ -271,7 +324,9 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
         hoist = 1;
         if (c.dim == 3 && v->G % (last * c.block_shape[c.dim - 2]) == 0) hoist = 2;
     }
-    HIP_TRY(v->fit(a, hoist, (hipStream_t)stream), "smoe_fit launch");
+    a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1];
+    if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
+    else HIP_TRY(v->fit(a, hoist, (hipStream_t)stream), "smoe_fit launch");
     // TF multiplies the beta powers after every apply (fp32 running product)
     for (int i = 0; i < n_iters; ++i) {
         s->beta1_power *= c.beta1;

@@ -24,6 +24,7 @@ struct KernelConsts {
     int use_det;        // smoe.py:809
     int train_gammas;   // smoe.py:841
     int only_y_gamma;   // gamma_mask: slopes only for channel 0 (smoe.py:725-729)
+    float sw[SMOE_MAX_CHANNELS];  // ssim_opt: SSIM channel weight / window count (smoe.py:1006-1009)
 };
 
 struct FitArgs {
@@ -43,6 +44,8 @@ struct FitArgs {
     float clip;
     float reg_pi;             // pis_l1 / start_pis
     float reg_u;              // u_l1
+    const float* ssim_T;      // ssim_opt: tap tables Tr [bh][bh], Tc [bw][bw] (null otherwise)
+    int bh, bw;
     KernelConsts kc;
 };
 
@@ -59,6 +62,8 @@ struct FwdArgs {
     const float* coords;
     int B, N, update_active;
     float reg_pi, reg_u;
+    const float* ssim_T;
+    int bh, bw;
     KernelConsts kc;
 };
 
@@ -91,6 +96,9 @@ struct Variant {
     hipError_t (*fwd)(const FwdArgs&, hipStream_t);
     size_t (*lds_bytes)(int N, bool has_lw);
     int (*fit_waves_per_cu)(int N, bool has_lw);
+    hipError_t (*fit_ssim)(const FitArgs&, int hoist_level, hipStream_t);   // ssim_opt (D == 2, G == 64)
+    hipError_t (*fwd_ssim)(const FwdArgs&, hipStream_t);
+    size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw);
 };
 
 // ---- shared-kernel image mode (smoe_shared.hip) ----------------------------------------------

@@ -227,10 +227,14 @@ struct PixelOut {
 //   acc[A_k,l,m]   += u_k x_l z'_m             (x, not x - mu: corrected in finish_partials)
 //   acc[nu_k,c]    += wt_k G_c     acc[ga_k,l,c] += wt_k G_c x_l
 // The influence slot accumulates sum_n wt_k (> 0 iff some pixel passes the mask, smoe.py:829).
-template <int D, int C, int K, bool TRAIN, int HL = 0>
+// EXTG (ssim_opt): dL/dq of the pixel comes from the caller (gext[c], the SSIM adjoint) instead of the
+// margin loss; the clip / fake-quant straight-through mask is still applied here and the loss slot is
+// left to the caller.
+template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false>
 __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                       const float (&x)[D], const float (&t)[C], float lw,
-                                      float* __restrict__ acc, PixelOut<D, C, K>& o) {
+                                      float* __restrict__ acc, PixelOut<D, C, K>& o,
+                                      const float* __restrict__ gext = nullptr) {
     using Lt = Layout<D, C, K>;
     float z[K][D], g[K];
     float S = 0.0f;
@@ -279,11 +283,11 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         const float ad = fabsf(diff) - kc.epsm;
         acc[Lt::S_SSE] = fmaf(diff, diff, acc[Lt::S_SSE]);
         const float cwl = kc.cw[c] * lw;
-        acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
+        if (!EXTG) acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
         if (TRAIN) {
             // sign(diff) in {-1,0,1}: |diff| is either 0 or >= 2^-30, so diff * 2^100 saturates the clamp
             const float sg = __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -1.0f, 1.0f);
-            const float gm = (cwl + cwl) * (ad * sg);
+            const float gm = EXTG ? gext[c] : (cwl + cwl) * (ad * sg);
             // clip_by_value / fake-quant straight-through: gradient only where neither clamp acted
             Gc[c] = (yc == y[c]) ? gm : 0.0f;
             dot = (c == 0) ? Gc[c] * y[c] : fmaf(Gc[c], y[c], dot);   // sum_k h_k w_k == sum_c G_c y_c
@@ -402,6 +406,15 @@ struct Tile {
     __host__ __device__ static size_t bytes(int N, bool has_lw, int CR = D) {
         return sizeof(float) * (size_t)(off_lw(N, CR) + (has_lw ? NB * N : 0));
     }
+    // ssim_opt (G == 64, one block per wavefront): the two tap tables of the workgroup, then per wavefront
+    // the planes X [C][N] (quantised reconstruction -> dL/dq), Wa [5][N] (column sums of x, x^2, xy, y, y^2;
+    // later the row pass of the adjoint) and Wb [3][N] (coefficient maps)
+    __host__ __device__ static int off_ssim(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * N : 0), 4); }
+    __host__ __device__ static int ssim_tabs(int bh, int bw) { return round_up(bh * bh + bw * bw, 4); }
+    __host__ __device__ static int ssim_wave(int N) { return round_up(C * N + 8 * N, 4); }
+    __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw) {
+        return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR) + ssim_tabs(bh, bw) + WAVES * ssim_wave(N));
+    }
 };
 
 template <int D, int C, int K, int G, int WAVES, int CR = D>
@@ -478,6 +491,164 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
 }
 
 // ---------------------------------------------------------------------------
+// SSIM loss stage (ssim_opt; smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d blocks.
+// One wavefront works on one block-channel plane held in LDS.  The reference pads the block SYMMETRIC
+// by 5 (smoe.py:993-996) and correlates with the 11x11 Gaussian (sigma 1.5, VALID): per axis that is
+// the b x b matrix  T[i][j] = sum_a g[a] * [mirror(i + a - 5) == j]  (symmetric, band |i - j| <= 5,
+// built on the host), so the window statistic is  Tr * plane * Tc  and its adjoint is the same
+// product on the coefficient maps -- no padded copy, no scatter.
+// ---------------------------------------------------------------------------
+constexpr float SSIM_C1 = 0.0001f;    // (0.01 * max_val)^2   image_ops_impl.py:74,110
+constexpr float SSIM_C2 = 0.0009f;    // (0.03 * max_val)^2   image_ops_impl.py:75,111
+
+// dst[p][i][j] = sum_r Tr[i][r] * f_p(r, j): window sums along axis 0 of x, x^2, x*y, y, y^2
+__device__ __forceinline__ void ssim_cols_products(float* __restrict__ dst, const float* __restrict__ xp,
+                                                   const float* __restrict__ yp, const float* __restrict__ Tr,
+                                                   int bh, int bw, int N, int lane) {
+    for (int n = lane; n < N; n += 64) {
+        const int i = n / bw;
+        const int j = n - i * bw;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int r = i + a - 5;
+            const bool ok = (r >= 0) && (r < bh);
+            const int rr = ok ? r : i;
+            const float w = ok ? Tr[i * bh + rr] : 0.0f;
+            const float xv = xp[rr * bw + j];
+            const float yv = yp[rr * bw + j];
+            const float wx = w * xv, wy = w * yv;
+            s0 += wx;
+            s1 = fmaf(wx, xv, s1);
+            s2 = fmaf(wx, yv, s2);
+            s3 += wy;
+            s4 = fmaf(wy, yv, s4);
+        }
+        dst[n] = s0;
+        dst[N + n] = s1;
+        dst[2 * N + n] = s2;
+        dst[3 * N + n] = s3;
+        dst[4 * N + n] = s4;
+    }
+}
+
+// dst[p][i][j] = sum_c Tc[j][c] * src[p][i][c]
+template <int NP>
+__device__ __forceinline__ void ssim_rows(float* __restrict__ dst, const float* __restrict__ src,
+                                          const float* __restrict__ Tc, int bw, int N, int lane) {
+    for (int n = lane; n < N; n += 64) {
+        const int i = n / bw;
+        const int j = n - i * bw;
+        float s[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int c = j + a - 5;
+            const bool ok = (c >= 0) && (c < bw);
+            const int cc = ok ? c : j;
+            const float w = ok ? Tc[j * bw + cc] : 0.0f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) s[p] = fmaf(w, src[p * N + i * bw + cc], s[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dst[p * N + n] = s[p];
+    }
+}
+
+// Row pass of the x-dependent sums + the SSIM formula per window position (image_ops_impl.py:110-129).
+// Returns this lane's sum of luminance * contrast-structure; with GRAD the three coefficient maps
+// scale * d(l*cs)/d{mu_x, E[x^2], E[xy]} go to dst.
+template <bool GRAD>
+__device__ __forceinline__ float ssim_rows_stats(float* __restrict__ dst, const float* __restrict__ src,
+                                                 const float* __restrict__ Tc, int bw, int N, int lane, float scale) {
+    float part = 0.0f;
+    for (int n = lane; n < N; n += 64) {
+        const int i = n / bw;
+        const int j = n - i * bw;
+        float mx = 0.0f, sx = 0.0f, pxy = 0.0f, my = 0.0f, sy = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int c = j + a - 5;
+            const bool ok = (c >= 0) && (c < bw);
+            const int cc = ok ? c : j;
+            const float w = ok ? Tc[j * bw + cc] : 0.0f;
+            mx = fmaf(w, src[i * bw + cc], mx);
+            sx = fmaf(w, src[N + i * bw + cc], sx);
+            pxy = fmaf(w, src[2 * N + i * bw + cc], pxy);
+            my = fmaf(w, src[3 * N + i * bw + cc], my);
+            sy = fmaf(w, src[4 * N + i * bw + cc], sy);
+        }
+        const float num0 = mx * my * 2.0f;
+        const float den0 = mx * mx + my * my;
+        const float N0 = num0 + SSIM_C1, D0 = den0 + SSIM_C1;
+        const float N1 = (pxy * 2.0f - num0) + SSIM_C2;
+        const float D1 = ((sx + sy) - den0) + SSIM_C2;
+        const float r0 = 1.0f / D0, r1 = 1.0f / D1;
+        const float lum = N0 * r0, cs = N1 * r1;
+        part = fmaf(lum, cs, part);
+        if (GRAD) {
+            const float dl = (2.0f * my - lum * (2.0f * mx)) * r0;             // d lum / d mu_x
+            const float dc = (cs * (2.0f * mx) - 2.0f * my) * r1;              // d cs / d mu_x
+            dst[n] = scale * fmaf(cs, dl, lum * dc);
+            dst[N + n] = scale * (-(lum * cs) * r1);                            // d / d E[x^2]
+            dst[2 * N + n] = scale * ((lum + lum) * r1);                        // d / d E[xy]
+        }
+    }
+    return part;
+}
+
+// Column pass of the adjoint + assembly of dL/dq:  g = Ga + 2 x Gb + y Gc, written over x in place.
+__device__ __forceinline__ void ssim_cols_adjoint(float* __restrict__ xp, const float* __restrict__ yp,
+                                                  const float* __restrict__ src, const float* __restrict__ Tr,
+                                                  int bh, int bw, int N, int lane) {
+    for (int n = lane; n < N; n += 64) {
+        const int i = n / bw;
+        const int j = n - i * bw;
+        float ga = 0.0f, gb = 0.0f, gc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int r = i + a - 5;
+            const bool ok = (r >= 0) && (r < bh);
+            const int rr = ok ? r : i;
+            const float w = ok ? Tr[i * bh + rr] : 0.0f;
+            ga = fmaf(w, src[rr * bw + j], ga);
+            gb = fmaf(w, src[N + rr * bw + j], gb);
+            gc = fmaf(w, src[2 * N + rr * bw + j], gc);
+        }
+        const float xv = xp[n];
+        xp[n] = fmaf(yp[n], gc, fmaf(xv + xv, gb, ga));
+    }
+}
+
+// 1 - SSIM of one block: returns this lane's share of -sum_c sw_c * mean(l * cs); with GRAD the plane
+// X[c] is replaced by dL/dq.  sw[c] = channel weight / window count (kc.sw).
+template <int C, bool GRAD>
+__device__ __forceinline__ float ssim_block(float* __restrict__ X, const float* __restrict__ tgt,
+                                            float* __restrict__ wa, float* __restrict__ wb,
+                                            const float* __restrict__ Tr, const float* __restrict__ Tc,
+                                            const float* __restrict__ sw, int bh, int bw, int N, int lane) {
+    float part = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        float* xp = X + c * N;
+        const float* yp = tgt + c * N;
+        ssim_cols_products(wa, xp, yp, Tr, bh, bw, N, lane);
+        wave_lds_sync();
+        const float swc = (c == 0) ? sw[0] : ((c == 1) ? sw[1] : sw[2]);   // no dynamic indexing of kernel arguments
+        part -= swc * ssim_rows_stats<GRAD>(wb, wa, Tc, bw, N, lane, -swc);
+        if (GRAD) {
+            wave_lds_sync();
+            ssim_rows<3>(wa, wb, Tc, bw, N, lane);
+            wave_lds_sync();
+            ssim_cols_adjoint(xp, yp, wa, Tr, bh, bw, N, lane);
+        }
+        wave_lds_sync();
+    }
+    return part;
+}
+
+// ---------------------------------------------------------------------------
 // fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
 // ---------------------------------------------------------------------------
 template <int D, int C, int K, bool HAS_LW, int HL>
@@ -505,7 +676,10 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // HL = number of trailing axes whose index is the same for every pixel n = i*G + sub of a lane: the host
 // guarantees G % (block_shape[D-1] * ... * block_shape[D-HL]) == 0.  Terms in those coordinates are
 // hoisted out of the pixel loop (HL = 1 for 16x16 blocks with G = 16; HL = 2 for 16x16x4 with G = 64).
-template <int D, int C, int K, int G, int WAVES, int HL>
+// SSIM (ssim_opt, G == 64 and D == 2 only): loss_pixel = 1 - SSIM.  Per iteration: a forward-only sweep
+// leaves the quantised reconstruction of the block in LDS, the wavefront turns it into dL/dq
+// (ssim_block), and the usual fused sweep runs with that gradient instead of the margin loss.
+template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false>
 __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -532,6 +706,17 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     const bool has_lw = a.loss_w != nullptr;
 
     stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    // ssim_opt planes (see Tile::off_ssim)
+    float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
+    const int bh = a.bh, bw = a.bw;
+    const float* s_Tr = s_ssim;
+    const float* s_Tc = s_ssim + bh * bh;
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N);
+    float* s_Wa = s_X + C * N;
+    float* s_Wb = s_Wa + 5 * N;
+    if (SSIM) {
+        for (int i = threadIdx.x; i < bh * bh + bw * bw; i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+    }
     float xc[D];                                   // coordinates of the lane's pixel i = 0 (hoisted axes: all its pixels)
 #pragma unroll
     for (int l = 0; l < D; ++l) xc[l] = a.coords[l * N + min(sub, N - 1)];
@@ -598,8 +783,43 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 }
             }
             if (HL > 0) hoist_const<D, C, K, HL>(R, xc);
-            if (has_lw) pixel_loop_train<D, C, K, true, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
-            else pixel_loop_train<D, C, K, false, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+            if constexpr (SSIM) {
+                // the reference's SSIM branch does not use loss_weights (smoe.py:929-1010)
+                const int pxl = (N + G - 1) / G;
+                for (int i = 0; i < pxl; ++i) {                 // sweep 1: reconstruction only
+                    const int n = i * G + sub;
+                    if (n < N) {
+                        float x[D], t[C], scratch_acc[Lt::NSLOT];
+#pragma unroll
+                        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+#pragma unroll
+                        for (int j = 0; j < Lt::NSLOT; ++j) scratch_acc[j] = 0.0f;
+                        PixelOut<D, C, K> o;
+                        pixel<D, C, K, false, HL>(R, kc, x, t, 1.0f, scratch_acc, o);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+                    }
+                }
+                wave_lds_sync();
+                acc[Lt::S_LOSS] = ssim_block<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, kc.sw, bh, bw, N, lane);
+                for (int i = 0; i < pxl; ++i) {                 // sweep 2: forward again + backward with dL/dq
+                    const int n = i * G + sub;
+                    if (n < N) {
+                        float x[D], t[C], gq[C];
+#pragma unroll
+                        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) { t[c] = s_tgt[c * N + n]; gq[c] = s_X[c * N + n]; }
+                        PixelOut<D, C, K> o;
+                        pixel<D, C, K, true, HL, true>(R, kc, x, t, 1.0f, acc, o, gq);
+                    }
+                }
+            } else {
+                if (has_lw) pixel_loop_train<D, C, K, true, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+                else pixel_loop_train<D, C, K, false, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+            }
             if (HL > 0) complete_const<D, C, K, HL>(xc, acc);
         }
         {
@@ -637,7 +857,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             newp[s] = upd ? p2 : pv;
             if (upd) { s_mv[2 * jc] = m2; s_mv[2 * jc + 1] = v2; }
             if (j == Lt::S_LOSS && !frozen) {
-                const float lossv = total[s] + reg_loss;
+                const float lossv = (SSIM ? 1.0f + total[s] : total[s]) + reg_loss;     // smoe.py:1010: 1 - ssim
                 last_loss = lossv;
                 bad = (lossv != lossv) || (has_loss0 && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f));
             }
@@ -691,7 +911,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 // ---------------------------------------------------------------------------
 // forward (evaluation) kernel
 // ---------------------------------------------------------------------------
-template <int D, int C, int K, int G, int WAVES>
+template <int D, int C, int K, int G, int WAVES, bool SSIM = false>
 __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -716,6 +936,16 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     const bool has_lw = a.loss_w != nullptr;
 
     stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    float* s_ssim = lds + T::off_ssim(N, has_lw, D);
+    const int bh = a.bh, bw = a.bw;
+    const float* s_Tr = s_ssim;
+    const float* s_Tc = s_ssim + bh * bh;
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N);
+    float* s_Wa = s_X + C * N;
+    float* s_Wb = s_Wa + 5 * N;
+    if (SSIM) {
+        for (int i = threadIdx.x; i < bh * bh + bw * bw; i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+    }
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
         const int j = sub + s * G;
@@ -752,6 +982,10 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             const float lw = has_lw ? s_lw[n] : 1.0f;
             PixelOut<D, C, K> o;
             pixel<D, C, K, false>(R, a.kc, x, t, lw, acc, o);
+            if (SSIM) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+            }
             if (valid_b) {
                 if (a.recon != nullptr) {
 #pragma unroll
@@ -777,6 +1011,10 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
         }
     }
 
+    if constexpr (SSIM) {                              // loss_pixel = 1 - SSIM (smoe.py:1006-1010)
+        wave_lds_sync();
+        acc[Lt::S_LOSS] = ssim_block<C, false>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, N, lane);
+    }
     float total[T::SPL];
     reduce_slots<D, C, K, G, WAVES, Layout<D, C, K>::NPAR>(acc, s_scratch, lane, total);
 
@@ -796,7 +1034,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
         for (int s = 0; s < T::SPL; ++s) {
             const int j = sub + s * G;
             if (j == Lt::S_LOSS) {
-                float lossv = total[s];
+                float lossv = SSIM ? 1.0f + total[s] : total[s];
                 if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
@@ -941,8 +1179,48 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ssim_opt launches: instantiated for 2-d blocks on the one-block-per-wavefront tiling only
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
+    if constexpr (D == 2 && G == 64) {
+        using T = Tile<D, C, K, G, WAVES>;
+        auto kern = fit_kernel<D, C, K, G, WAVES, 0, true>;
+        int hl = 0;
+        if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        const int grid = (a.B + T::NB - 1) / T::NB;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
+    if constexpr (D == 2 && G == 64) {
+        using T = Tile<D, C, K, G, WAVES>;
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw);
+        auto kern = forward_kernel<D, C, K, G, WAVES, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        const int grid = (a.B + T::NB - 1) / T::NB;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
 template <int D, int C, int K, int G, int WAVES>
 size_t lds_bytes(int N, bool has_lw) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw); }
+
+template <int D, int C, int K, int G, int WAVES>
+size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw) {
+    return (D == 2 && G == 64) ? Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw) : (size_t)-1;
+}
 
 template <int D, int C, int K, int G, int WAVES>
 int fit_occupancy(int N, bool has_lw) {
@@ -956,7 +1234,8 @@ int fit_occupancy(int N, bool has_lw) {
 }
 
 #define SMOE_VARIANT(D, C, K, G, W) \
-    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W> }
+    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
+      &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W> }
 
 static const Variant g_variants[] = {
     SMOE_VARIANT(2, 1, 4, 16, 4), SMOE_VARIANT(2, 1, 4, 64, 2),

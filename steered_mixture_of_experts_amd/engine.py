@@ -41,6 +41,7 @@ class EngineConfig:
     u_l1: float = 0.0
     start_pis: int = 0
     only_y_gamma: bool = False
+    ssim_opt: bool = False
 
     @property
     def dim(self) -> int:
@@ -104,6 +105,7 @@ class BlockEngine:
         c.pis_l1, c.u_l1 = cfg.pis_l1, cfg.u_l1
         c.start_pis = cfg.start_pis or cfg.kernels
         c.only_y_gamma = int(cfg.only_y_gamma)
+        c.ssim_opt = int(cfg.ssim_opt)
         self._c = c
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_create(C.byref(self._h), C.byref(c)))

@@ -56,7 +56,7 @@ class Smoe:
                  only_rec_from_checkpoint=False, loss_mask=None, device=None, engine_factory=None):
         # -- options outside the hot path: refuse loudly ---------------------------------
         unsupported = {
-            "radial_as": radial_as, "ssim_opt": ssim_opt,
+            "radial_as": radial_as,
             "train_svs": train_svs, "train_trafo": train_trafo, "train_inverse_cov": train_inverse_cov,
             "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
         }
@@ -119,6 +119,17 @@ class Smoe:
         self.num_blocks = int(np.prod(self.grid))
         self.start_batches = self.num_blocks                             # smoe.py:247
         self.padded = blk.padded_shape(image.shape[:d], bs) != tuple(image.shape[:d])
+        if self.ssim_opt:
+            # loss_pixel = 1 - SSIM (smoe.py:929,980-1011).  The reference's SSIM branch ignores the per-pixel loss
+            # weights, so neither a loss mask nor the edge-replicated padding of ragged images can be honoured.
+            if d != 2:
+                raise NotImplementedError("ssim_opt is built for images (2-d blocks); the reference pads the time "
+                                          "axis by 5 as well, which needs at least 5 frames per block")
+            if min(bs) < 5:
+                raise ValueError("ssim_opt pads every block SYMMETRIC by 5: blocks need at least 5 pixels per axis")
+            if loss_mask is not None or self.padded:
+                raise NotImplementedError("ssim_opt ignores loss weights (as the reference does): no loss_mask, and "
+                                          "the image must be a multiple of the block shape")
 
         # -- shard the independent blocks over ranks ------------------------
         self.rank, self.world_size = sdist.world()
@@ -215,7 +226,7 @@ class Smoe:
             beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999,
             adam_eps=o1._epsilon if o1 else 1e-8,
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
-            start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma))
+            start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma), ssim_opt=bool(self.ssim_opt))
         key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
         key = repr(key)
         if key != self._engine_key:

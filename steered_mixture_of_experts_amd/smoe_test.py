@@ -8,8 +8,8 @@ three Adam optimizers with ``base_lr``, ``base_lr/lr_div``, ``base_lr*lr_mult``
 ``--mode blocks`` (default): every ``-bz`` block is an independent model with ``-k`` kernels per axis
 (the per-block hot path).  ``--mode shared``: the reference's whole-image fit -- ``-k`` is the GLOBAL
 kernel grid and ``-bz`` the pixel batch of a pass.  Flags of features that are not built (kernel
-adding, support vectors, motion models, SSIM, fake-quant training, sampling; batch overlap outside
-``--mode shared``) are
+adding, support vectors, motion models, fake-quant training, sampling; batch overlap outside
+``--mode shared``, SSIM outside ``--mode blocks``) are
 accepted for command-line compatibility but must keep their inactive values.
 """
 import argparse
@@ -91,7 +91,7 @@ def build_parser():
 def main(args):
     if len(args.bit_depths) != 5:
         raise ValueError("Number of bit depths must be five!")                        # smoe_test.py:24-25
-    inactive = {"inc_steps": 0, "radial_as": False, "ssim_opt": False, "sampling_percentage": 100,
+    inactive = {"inc_steps": 0, "radial_as": False, "sampling_percentage": 100,
                 "svreg": 0, "hpc_mode": False, "kernel_count_norm_l1": False,
                 "train_svs": False, "train_trafo": False, "train_inverse_cov": False,
                 "only_rec_from_checkpoint": False, "checkpoint_path": None}
@@ -123,9 +123,9 @@ def main(args):
         smoe = Smoe(orig, kpd, use_diff_center=args.use_diff_center, quantization_mode=args.quantization_mode,
                     bit_depths=args.bit_depths, quantize_pis=args.quantize_pis and args.quantization_mode >= 1,
                     lower_bounds=args.lower_bounds, upper_bounds=args.upper_bounds, only_y_gamma=only_y_gamma,
-                    loss_mask=loss_mask, **common)
+                    loss_mask=loss_mask, ssim_opt=args.ssim_opt, **common)
     else:
-        if args.use_diff_center or only_y_gamma or args.quantization_mode or loss_mask is not None:
+        if args.use_diff_center or only_y_gamma or args.quantization_mode or loss_mask is not None or args.ssim_opt:
             raise NotImplementedError("--mode shared supports the plain model only")
         smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, **common)
     optimizer1 = Adam(args.base_lr)                                                   # smoe_test.py:84-86

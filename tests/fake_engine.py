@@ -38,7 +38,8 @@ class OracleEngine:
             train_pis=cfg.train_pis, train_gammas=cfg.train_gammas, train_musx=cfg.train_musx,
             lr_expert=cfg.lr_expert, lr_pis=cfg.lr_pis, lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2,
             adam_eps=cfg.adam_eps, grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1,
-            start_pis=cfg.start_pis or cfg.kernels, only_y_gamma=getattr(cfg, 'only_y_gamma', False))
+            start_pis=cfg.start_pis or cfg.kernels, only_y_gamma=getattr(cfg, 'only_y_gamma', False),
+            ssim_opt=getattr(cfg, 'ssim_opt', False))
         self.coords = np.ascontiguousarray(o.block_coords(cfg.block_shape).T)
 
     def close(self):
@@ -56,8 +57,8 @@ class OracleEngine:
         B = target.shape[0]
         act = active.numpy().view(np.uint32)
         p = self._np(params)
-        if want_argmax or want_gate:
-            # the C oracle has no argmax / gate outputs: use the numpy one for those
+        if want_argmax or want_gate or self.ocfg.ssim_opt:
+            # the C oracle has no argmax / gate outputs and no SSIM loss: use the numpy one for those
             K = self.cfg.kernels
             mask = ((act[:, None] >> np.arange(K, dtype=np.uint32)[None, :]) & 1).astype(bool)
             tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
@@ -79,6 +80,8 @@ class OracleEngine:
             sse_out=None):
         act = active.numpy().view(np.uint32)
         state.beta_pow[:] = [state.c.beta1_power, state.c.beta2_power]      # restore() writes the c fields
+        if self.ocfg.ssim_opt:
+            return self._fit_numpy(target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out)
         r = co.fit(self.ocfg, self.coords, target.numpy(), self._np(params), self._np(state.m), self._np(state.v), act,
                    n_iters, state.beta_pow, None if loss_w is None else loss_w.numpy(),
                    None if diverged is None else diverged.numpy().view(np.uint32),
@@ -89,6 +92,39 @@ class OracleEngine:
             loss_out.copy_(torch.from_numpy(r["loss"]))
         if sse_out is not None:
             sse_out.copy_(torch.from_numpy(r["sse"]))
+
+    def _fit_numpy(self, target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out):
+        """The iteration body of oracle.fit (pass -> prune -> Adam -> divergence test) on the numpy oracle."""
+        K = self.cfg.kernels
+        shifts = np.arange(K, dtype=np.uint32)[None, :]
+        tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
+        p = self._np(params)
+        st = {"m": self._np(state.m), "v": self._np(state.v), "t": 0,
+              "b1p": np.float32(state.beta_pow[0]), "b2p": np.float32(state.beta_pow[1])}
+        stopped = np.zeros((tgt.shape[0],), bool) if diverged is None else diverged.numpy().view(np.uint32).astype(bool)
+        f = None
+        for _ in range(n_iters):
+            mask = ((act[:, None] >> shifts) & 1).astype(bool)
+            f = o.forward(p, tgt, self.coords.T, mask, self.ocfg, None, np.float32, want_grads=True)
+            new = np.where(stopped[:, None], mask, f["active_new"])
+            act[:] = (new.astype(np.uint32) << shifts).sum(axis=1).astype(np.uint32)
+            p = o.adam_step(p, f["grads"], st, self.ocfg, np.float32, frozen=stopped)
+            if loss0 is not None:
+                l0 = loss0.numpy()
+                stopped = stopped | np.isnan(f["loss"]) | (f["loss"] + 1 > (l0 + 100) * 10)
+        for k in NAMES:
+            params[k].copy_(torch.from_numpy(np.ascontiguousarray(p[k], dtype=np.float32)))
+            state.m[k].copy_(torch.from_numpy(np.ascontiguousarray(st["m"][k], dtype=np.float32)))
+            state.v[k].copy_(torch.from_numpy(np.ascontiguousarray(st["v"][k], dtype=np.float32)))
+        state.beta_pow[:] = [st["b1p"], st["b2p"]]
+        state._step = int(state.c.step) + n_iters
+        state.c.beta1_power, state.c.beta2_power, state.c.step = float(st["b1p"]), float(st["b2p"]), state._step
+        if diverged is not None:
+            diverged.numpy().view(np.uint32)[:] = stopped.astype(np.uint32)
+        if loss_out is not None and f is not None:
+            loss_out.copy_(torch.from_numpy(f["loss"].astype(np.float32)))
+        if sse_out is not None and f is not None:
+            sse_out.copy_(torch.from_numpy(f["sse"].astype(np.float32)))
 
     def update_kernel_list(self, params, active):
         K = self.cfg.kernels

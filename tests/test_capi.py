@@ -57,7 +57,7 @@ def test_no_cpu_fallback_without_a_device():
     from steered_mixture_of_experts_amd import _lib
     lib = _lib.load()
     c = _lib.SmoeConfig()
-    c.abi_version, c.dim, c.channels, c.kernels, c.precision = 1, 2, 1, 4, 8
+    c.abi_version, c.dim, c.channels, c.kernels, c.precision = _lib.SMOE_ABI_VERSION, 2, 1, 4, 8
     c.block_shape[0] = c.block_shape[1] = 16
     c.block_shape[2] = 1
     h = C.c_void_p()
@@ -77,7 +77,7 @@ def test_argument_validation_messages():
     c.abi_version = 99
     assert lib.smoe_create(C.byref(h), C.byref(c)) == _lib.SMOE_ERR_INVALID
     assert b"abi_version" in lib.smoe_last_error()
-    c.abi_version, c.dim = 1, 5
+    c.abi_version, c.dim = _lib.SMOE_ABI_VERSION, 5
     assert lib.smoe_create(C.byref(h), C.byref(c)) == _lib.SMOE_ERR_INVALID
     assert lib.smoe_forward(None, 1, None, None, None, None, None, None, None, None, None, 0, None) == _lib.SMOE_ERR_INVALID
 

@@ -108,7 +108,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
-    for kw in ({"ssim_opt": True}, {"quantization_mode": 2}, {"overlap_of_batches": 2}, {"add_kernel_slots": 4},
+    for kw in ({"quantization_mode": 2}, {"overlap_of_batches": 2}, {"add_kernel_slots": 4},
                {"train_svs": True}, {"radial_as": True}, {"train_inverse_cov": True}, {"quantization_mode": 3}):
         with pytest.raises(NotImplementedError):
             Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
@@ -289,9 +289,37 @@ def test_training_cli_mirrors_the_reference_flags(tmp_path):
         g = cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "3", "-bz", "16", "16",
                                         "-n", "2", "-v", "2", "--mode", "shared"]))
         assert g.kernels == 9 and g.num_batches == 6
+        q = cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "2", "-bz", "16", "16",
+                                        "-n", "2", "-v", "2", "-ssim", "true"]))
+        assert q.ssim_opt and 0.0 < q.get_losses()[-1][1] < 1.0            # 1 - SSIM
         with pytest.raises(NotImplementedError):
-            cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-ssim", "true"]))
+            cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "3", "-bz", "16", "16",
+                                        "-ssim", "true", "--mode", "shared"]))
         with pytest.raises(NotImplementedError):
             cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-is", "100"]))
     finally:
         smod._default_engine_factory, smod._default_shared_factory = f1, f2
+
+
+def test_ssim_opt_fits_one_minus_ssim():
+    """ssim_opt (smoe.py:929,980-1011): the facade trains on 1 - SSIM; losses follow oracle.fit with ssim_opt."""
+    img = _image(32, 32, seed=12)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, ssim_opt=True,
+             engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(6, val_iter=3)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4, lr_steer=0.01, ssim_opt=True)
+    p0 = o.init_params(tb, [2, 2])
+    pn, _, info = o.fit(p0, tb.reshape(4, -1, 1), o.block_coords((16, 16)), cfg, 6, val_iter=3, dtype=np.float32)
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k], rtol=1e-5, atol=1e-6), k
+    losses = [v for _, v in s.get_losses()]
+    assert 0.0 < losses[-1] < losses[0] < 1.0
+    for kw in ({"loss_mask": np.ones((32, 32), np.float32)}, {"batch_size": [12, 12]}):
+        with pytest.raises(NotImplementedError):
+            Smoe(img, **{"kernels_per_dim": [2, 2], "batch_size": [16, 16], "ssim_opt": True,
+                         "engine_factory": OracleEngine, **kw})
+    with pytest.raises(ValueError):
+        Smoe(img, kernels_per_dim=[2, 2], batch_size=[4, 16], ssim_opt=True, engine_factory=OracleEngine)
