@@ -77,7 +77,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed steps; the default is one full launch so that every fit launch of a default run has the same size")
     ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU")
     ap.add_argument("--iters-per-launch", type=int, default=100)
     ap.add_argument("--tiling", type=int, default=0, help="lanes per block: 0 auto, 16, 64")

@@ -43,5 +43,7 @@ if __name__ == "__main__":
         out.append(run(B, shape, C, kpd, 50, False, 0))
         out.append(run(B, shape, C, kpd, 50, False, 64))
         out.append(run(B, shape, C, kpd, 50, True, 0))
+        if tuple(shape) == (16, 16):
+            out.append(run(B, shape, C, kpd, 50, True, 64))
     for r in out:
         print(json.dumps(r))

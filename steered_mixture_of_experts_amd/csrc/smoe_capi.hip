@@ -17,7 +17,8 @@ struct smoe_context {
     int N;
     float* d_coords;     // [D][N]
     float* d_probes;     // [D][3]
-    float* d_ssim_T;     // ssim_opt: tap tables Tr [bh][bh], Tc [bw][bw]
+    float* d_ssim_T;     // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
+    double* d_partials;  // workspace of smoe_reduce_scalars
     int force_g;
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
@@ -59,7 +60,7 @@ bool params_ok(const smoe_params* p) {
 
 // ssim_opt: per axis the b x b matrix of "SYMMETRIC pad by 5, correlate with the 11-tap Gaussian, VALID"
 // (smoe.py:993-996; image_ops_impl.py:132-149: softmax of -0.5 (a-5)^2 / 1.5^2, separable):
-// T[i][j] = sum_a g[a] [mirror(i + a - 5) == j]
+// T[i][j] = sum_a g[a] [mirror(i + a - 5) == j], stored banded: out[i][a] = T[i][i + a - 5], 0 outside the axis
 void ssim_axis_table(int b, float* out) {
     double g[11], sum = 0.0;
     for (int a = 0; a < 11; ++a) { g[a] = std::exp(-0.5 * (a - 5) * (a - 5) / (1.5 * 1.5)); sum += g[a]; }
@@ -71,7 +72,11 @@ void ssim_axis_table(int b, float* out) {
             if (r >= b) r = 2 * b - 1 - r;
             T[(size_t)i * b + r] += g[a] / sum;
         }
-    for (size_t i = 0; i < T.size(); ++i) out[i] = (float)T[i];
+    for (int i = 0; i < b; ++i)
+        for (int a = 0; a < 11; ++a) {
+            const int j = i + a - 5;
+            out[(size_t)i * 11 + a] = (j >= 0 && j < b) ? (float)T[(size_t)i * b + j] : 0.0f;
+        }
 }
 
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
@@ -83,12 +88,15 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
     // Large blocks (>= 1024 pixels) always use a whole wavefront per block: 16 lanes would leave 64+
     // pixels per lane, and with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
     int want = h->force_g ? h->force_g : ((num_blocks >= 8192 && h->N <= 512) ? 16 : 64);
-    if (h->cfg.ssim_opt) want = 64;                  // the SSIM stage works on one block per wavefront
     const smoe::Variant* fallback = nullptr;
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels) continue;
         if (h->cfg.ssim_opt) {
-            if (v[i].G != 64) continue;
+            // 16x16 blocks: the register/DPP SSIM stage on the 16-lanes-per-block tiling; any other shape: the
+            // LDS stage with one block per wavefront
+            const bool b16 = h->cfg.block_shape[0] == 16 && h->cfg.block_shape[1] == 16;
+            const int g = h->force_g ? h->force_g : (b16 ? 16 : 64);
+            if (v[i].G != g) continue;
             if (v[i].lds_bytes_ssim(h->N, has_lw, h->cfg.block_shape[0], h->cfg.block_shape[1]) > 160u * 1024u) continue;
             return &v[i];
         }
@@ -155,6 +163,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->d_coords = nullptr;
     h->d_probes = nullptr;
     h->d_ssim_T = nullptr;
+    h->d_partials = nullptr;
     const int D = cfg->dim;
 
     // per-pixel coordinates [D][N], 'ij' meshgrid flattened row-major (smoe.py:2418-2421,1650)
@@ -181,11 +190,12 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_probes, sizeof(float) * D * 3);
     if (e == hipSuccess) e = hipMemcpy(h->d_coords, h->h_coords.data(), sizeof(float) * D * N, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * D * 3, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&h->d_partials, sizeof(double) * smoe::reduce_partials_count());
     if (e == hipSuccess && cfg->ssim_opt) {
         const int bh = cfg->block_shape[0], bw = cfg->block_shape[1];
-        std::vector<float> tabs((size_t)bh * bh + (size_t)bw * bw);
+        std::vector<float> tabs((size_t)11 * (bh + bw));
         ssim_axis_table(bh, tabs.data());
-        ssim_axis_table(bw, tabs.data() + (size_t)bh * bh);
+        ssim_axis_table(bw, tabs.data() + (size_t)11 * bh);
         e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
     }
@@ -193,6 +203,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         if (h->d_coords) (void)hipFree(h->d_coords);
         if (h->d_probes) (void)hipFree(h->d_probes);
         if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
+        if (h->d_partials) (void)hipFree(h->d_partials);
         delete h;
         return fail_hip(e, "smoe_create: workspace");
     }
@@ -235,6 +246,7 @@ int smoe_destroy(smoe_handle h) {
     if (h->d_coords) (void)hipFree(h->d_coords);
     if (h->d_probes) (void)hipFree(h->d_probes);
     if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
+    if (h->d_partials) (void)hipFree(h->d_partials);
     delete h;
     return SMOE_OK;
 }
@@ -370,7 +382,7 @@ int smoe_reduce_scalars(smoe_handle h, int32_t num_blocks, const float* loss, co
     if (num_blocks < 0 || !out_dev) return fail(SMOE_ERR_INVALID, "smoe_reduce_scalars: bad argument");
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::ReduceArgs a;
-    a.loss = loss; a.sse = sse; a.active = active; a.out = out_dev; a.B = num_blocks; a.N = h->N;
+    a.loss = loss; a.sse = sse; a.active = active; a.out = out_dev; a.partials = h->d_partials; a.B = num_blocks; a.N = h->N;
     HIP_TRY(smoe::launch_reduce(a, (hipStream_t)stream), "smoe_reduce_scalars launch");
     return SMOE_OK;
 }

@@ -44,7 +44,7 @@ struct FitArgs {
     float clip;
     float reg_pi;             // pis_l1 / start_pis
     float reg_u;              // u_l1
-    const float* ssim_T;      // ssim_opt: tap tables Tr [bh][bh], Tc [bw][bw] (null otherwise)
+    const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11] (null otherwise)
     int bh, bw;
     KernelConsts kc;
 };
@@ -86,6 +86,7 @@ struct ReduceArgs {
     const float* sse;
     const uint32_t* active;
     double* out;
+    double* partials;         // [reduce_partials_count()] workspace of the handle
     int B, N;
 };
 
@@ -152,6 +153,7 @@ const Variant* variants(int* count);
 hipError_t launch_readmit(const ReadmitArgs& a, int D, hipStream_t st);
 hipError_t launch_best(const BestArgs& a, hipStream_t st);
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st);
+int reduce_partials_count();
 
 }  // namespace smoe
 #endif

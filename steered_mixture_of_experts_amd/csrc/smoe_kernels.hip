@@ -410,8 +410,9 @@ struct Tile {
     // the planes X [C][N] (quantised reconstruction -> dL/dq), Wa [5][N] (column sums of x, x^2, xy, y, y^2;
     // later the row pass of the adjoint) and Wb [3][N] (coefficient maps)
     __host__ __device__ static int off_ssim(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * N : 0), 4); }
-    __host__ __device__ static int ssim_tabs(int bh, int bw) { return round_up(bh * bh + bw * bw, 4); }
-    __host__ __device__ static int ssim_wave(int N) { return round_up(C * N + 8 * N, 4); }
+    // G == 16 (16x16 blocks only): the SSIM stage runs in registers (ssim_block16), LDS holds just X per block
+    __host__ __device__ static int ssim_tabs(int bh, int bw) { return (G == 16) ? 0 : round_up(11 * (bh + bw), 4); }
+    __host__ __device__ static int ssim_wave(int N) { return (G == 16) ? BPW * C * N : round_up(C * N + 8 * N, 4); }
     __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw) {
         return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR) + ssim_tabs(bh, bw) + WAVES * ssim_wave(N));
     }
@@ -501,23 +502,34 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
 constexpr float SSIM_C1 = 0.0001f;    // (0.01 * max_val)^2   image_ops_impl.py:74,110
 constexpr float SSIM_C2 = 0.0009f;    // (0.03 * max_val)^2   image_ops_impl.py:75,111
 
+// Walk of the outputs n = lane, lane + 64, ... of one plane as (row i, column j) without a division per step.
+struct SsimWalk {
+    int i, j, di, dj;      // current position; per-step increments 64 / bw and 64 % bw
+    __device__ __forceinline__ SsimWalk(int lane, int bw) : i(lane / bw), j(lane - (lane / bw) * bw), di(64 / bw), dj(64 % bw) {}
+    __device__ __forceinline__ void next(int bw) {
+        j += dj; i += di;
+        if (j >= bw) { j -= bw; i += 1; }
+    }
+};
+
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+// Tap tables are banded: Tb[i][a] = T[i][i + a - 5], zero where i + a - 5 leaves the axis, so a tap is
+// weight * plane[clamp(i + a - 5)] with no compare / select.
 // dst[p][i][j] = sum_r Tr[i][r] * f_p(r, j): window sums along axis 0 of x, x^2, x*y, y, y^2
 __device__ __forceinline__ void ssim_cols_products(float* __restrict__ dst, const float* __restrict__ xp,
-                                                   const float* __restrict__ yp, const float* __restrict__ Tr,
+                                                   const float* __restrict__ yp, const float* __restrict__ Trb,
                                                    int bh, int bw, int N, int lane) {
-    for (int n = lane; n < N; n += 64) {
-        const int i = n / bw;
-        const int j = n - i * bw;
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Trb + w.i * 11;
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
 #pragma unroll
         for (int a = 0; a < 11; ++a) {
-            const int r = i + a - 5;
-            const bool ok = (r >= 0) && (r < bh);
-            const int rr = ok ? r : i;
-            const float w = ok ? Tr[i * bh + rr] : 0.0f;
-            const float xv = xp[rr * bw + j];
-            const float yv = yp[rr * bw + j];
-            const float wx = w * xv, wy = w * yv;
+            const int o = clampi(w.i + a - 5, bh - 1) * bw + w.j;
+            const float wt = tw[a];
+            const float xv = xp[o], yv = yp[o];
+            const float wx = wt * xv, wy = wt * yv;
             s0 += wx;
             s1 = fmaf(wx, xv, s1);
             s2 = fmaf(wx, yv, s2);
@@ -535,49 +547,47 @@ __device__ __forceinline__ void ssim_cols_products(float* __restrict__ dst, cons
 // dst[p][i][j] = sum_c Tc[j][c] * src[p][i][c]
 template <int NP>
 __device__ __forceinline__ void ssim_rows(float* __restrict__ dst, const float* __restrict__ src,
-                                          const float* __restrict__ Tc, int bw, int N, int lane) {
-    for (int n = lane; n < N; n += 64) {
-        const int i = n / bw;
-        const int j = n - i * bw;
+                                          const float* __restrict__ Tcb, int bw, int N, int lane) {
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Tcb + w.j * 11;
+        const int row = w.i * bw;
         float s[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) s[p] = 0.0f;
 #pragma unroll
         for (int a = 0; a < 11; ++a) {
-            const int c = j + a - 5;
-            const bool ok = (c >= 0) && (c < bw);
-            const int cc = ok ? c : j;
-            const float w = ok ? Tc[j * bw + cc] : 0.0f;
+            const int o = row + clampi(w.j + a - 5, bw - 1);
+            const float wt = tw[a];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) s[p] = fmaf(w, src[p * N + i * bw + cc], s[p]);
+            for (int p = 0; p < NP; ++p) s[p] = fmaf(wt, src[p * N + o], s[p]);
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) dst[p * N + n] = s[p];
     }
 }
 
-// Row pass of the x-dependent sums + the SSIM formula per window position (image_ops_impl.py:110-129).
+// Row pass of the five sums + the SSIM formula per window position (image_ops_impl.py:110-129).
 // Returns this lane's sum of luminance * contrast-structure; with GRAD the three coefficient maps
 // scale * d(l*cs)/d{mu_x, E[x^2], E[xy]} go to dst.
 template <bool GRAD>
 __device__ __forceinline__ float ssim_rows_stats(float* __restrict__ dst, const float* __restrict__ src,
-                                                 const float* __restrict__ Tc, int bw, int N, int lane, float scale) {
+                                                 const float* __restrict__ Tcb, int bw, int N, int lane, float scale) {
     float part = 0.0f;
-    for (int n = lane; n < N; n += 64) {
-        const int i = n / bw;
-        const int j = n - i * bw;
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Tcb + w.j * 11;
+        const int row = w.i * bw;
         float mx = 0.0f, sx = 0.0f, pxy = 0.0f, my = 0.0f, sy = 0.0f;
 #pragma unroll
         for (int a = 0; a < 11; ++a) {
-            const int c = j + a - 5;
-            const bool ok = (c >= 0) && (c < bw);
-            const int cc = ok ? c : j;
-            const float w = ok ? Tc[j * bw + cc] : 0.0f;
-            mx = fmaf(w, src[i * bw + cc], mx);
-            sx = fmaf(w, src[N + i * bw + cc], sx);
-            pxy = fmaf(w, src[2 * N + i * bw + cc], pxy);
-            my = fmaf(w, src[3 * N + i * bw + cc], my);
-            sy = fmaf(w, src[4 * N + i * bw + cc], sy);
+            const int o = row + clampi(w.j + a - 5, bw - 1);
+            const float wt = tw[a];
+            mx = fmaf(wt, src[o], mx);
+            sx = fmaf(wt, src[N + o], sx);
+            pxy = fmaf(wt, src[2 * N + o], pxy);
+            my = fmaf(wt, src[3 * N + o], my);
+            sy = fmaf(wt, src[4 * N + o], sy);
         }
         const float num0 = mx * my * 2.0f;
         const float den0 = mx * mx + my * my;
@@ -600,21 +610,19 @@ __device__ __forceinline__ float ssim_rows_stats(float* __restrict__ dst, const 
 
 // Column pass of the adjoint + assembly of dL/dq:  g = Ga + 2 x Gb + y Gc, written over x in place.
 __device__ __forceinline__ void ssim_cols_adjoint(float* __restrict__ xp, const float* __restrict__ yp,
-                                                  const float* __restrict__ src, const float* __restrict__ Tr,
+                                                  const float* __restrict__ src, const float* __restrict__ Trb,
                                                   int bh, int bw, int N, int lane) {
-    for (int n = lane; n < N; n += 64) {
-        const int i = n / bw;
-        const int j = n - i * bw;
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Trb + w.i * 11;
         float ga = 0.0f, gb = 0.0f, gc = 0.0f;
 #pragma unroll
         for (int a = 0; a < 11; ++a) {
-            const int r = i + a - 5;
-            const bool ok = (r >= 0) && (r < bh);
-            const int rr = ok ? r : i;
-            const float w = ok ? Tr[i * bh + rr] : 0.0f;
-            ga = fmaf(w, src[rr * bw + j], ga);
-            gb = fmaf(w, src[N + rr * bw + j], gb);
-            gc = fmaf(w, src[2 * N + rr * bw + j], gc);
+            const int o = clampi(w.i + a - 5, bh - 1) * bw + w.j;
+            const float wt = tw[a];
+            ga = fmaf(wt, src[o], ga);
+            gb = fmaf(wt, src[N + o], gb);
+            gc = fmaf(wt, src[2 * N + o], gc);
         }
         const float xv = xp[n];
         xp[n] = fmaf(yp[n], gc, fmaf(xv + xv, gb, ga));
@@ -644,6 +652,130 @@ __device__ __forceinline__ float ssim_block(float* __restrict__ X, const float* 
             ssim_cols_adjoint(xp, yp, wa, Tr, bh, bw, N, lane);
         }
         wave_lds_sync();
+    }
+    return part;
+}
+
+// ---------------------------------------------------------------------------
+// SSIM stage for 16x16 blocks on the 16-lanes-per-block tiling, entirely in registers: lane `sub` of a
+// block owns image column `sub` (pixels n = i*16 + sub), so
+//   * the column pass (axis 0) is in-lane: out[i] = sum_r T16[i][r] in[r] with COMPILE-TIME weights
+//     (the 16x16 tap matrix is folded to literals, zero taps vanish);
+//   * the row pass (axis 1) is across the 16 lanes of the block = one DPP row: eleven row_shl / row_shr
+//     shifted operands (bound_ctrl: lanes outside the row read 0) times per-lane weights
+//     wj[a] = T16[sub][sub + a - 5].
+// No LDS traffic besides reading q / target and writing dL/dq, no barriers.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr float ssim_gauss(int a) {      // image_ops_impl.py:132-149, size 11, sigma 1.5
+    constexpr float g[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.6000773311e-02f, 1.0936068743e-01f,
+                             2.1300554276e-01f, 2.6601171494e-01f, 2.1300554276e-01f, 1.0936068743e-01f,
+                             3.6000773311e-02f, 7.5987582095e-03f, 1.0283801239e-03f};
+    return g[a];
+}
+__host__ __device__ constexpr float ssim_t16(int i, int r) {  // SYMMETRIC pad 5 + 11 taps on a 16-sample axis
+    float s = 0.0f;
+    for (int a = 0; a < 11; ++a) {
+        int m = i + a - 5;
+        if (m < 0) m = -1 - m;
+        if (m >= 16) m = 31 - m;
+        if (m == r) s += ssim_gauss(a);
+    }
+    return s;
+}
+
+template <int NQ>
+__device__ __forceinline__ void ssim_colpass16(const float (&in)[NQ][16], float (&out)[NQ][16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) out[q][i] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float w = ssim_t16(i, r);
+            if (w != 0.0f) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) out[q][i] = fmaf(w, in[q][r], out[q][i]);
+            }
+        }
+    }
+}
+
+// value of lane (L + SH) of the same 16-lane row, 0 when that lane is outside the row
+template <int SH>
+__device__ __forceinline__ float ssim_row_neighbour(float v) {
+    constexpr int ctrl = (SH > 0) ? (0x100 + SH) : (0x110 - SH);   // row_shl:SH / row_shr:-SH
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float ssim_rowpass16(float v, const float (&wj)[11]) {
+    float s = wj[5] * v;
+    s = fmaf(wj[6], ssim_row_neighbour<1>(v), s);
+    s = fmaf(wj[4], ssim_row_neighbour<-1>(v), s);
+    s = fmaf(wj[7], ssim_row_neighbour<2>(v), s);
+    s = fmaf(wj[3], ssim_row_neighbour<-2>(v), s);
+    s = fmaf(wj[8], ssim_row_neighbour<3>(v), s);
+    s = fmaf(wj[2], ssim_row_neighbour<-3>(v), s);
+    s = fmaf(wj[9], ssim_row_neighbour<4>(v), s);
+    s = fmaf(wj[1], ssim_row_neighbour<-4>(v), s);
+    s = fmaf(wj[10], ssim_row_neighbour<5>(v), s);
+    s = fmaf(wj[0], ssim_row_neighbour<-5>(v), s);
+    return s;
+}
+
+// Same contract as ssim_block for one 16x16 block handled by 16 lanes: X [C][256] holds q and receives
+// dL/dq; returns the lane's share of -sum_c sw_c * sum(l * cs).
+template <int C, bool GRAD>
+__device__ __forceinline__ float ssim_block16(float* __restrict__ X, const float* __restrict__ tgt, int sub,
+                                              const float (&wj)[11], const float* __restrict__ sw) {
+    float part = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        const float swc = (c == 0) ? sw[0] : ((c == 1) ? sw[1] : sw[2]);
+        float* xp = X + c * 256 + sub;
+        const float* yp = tgt + c * 256 + sub;
+        float in[5][16], v[5][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float xv = xp[i * 16], yv = yp[i * 16];
+            in[0][i] = xv; in[1][i] = xv * xv; in[2][i] = xv * yv; in[3][i] = yv; in[4][i] = yv * yv;
+        }
+        ssim_colpass16<5>(in, v);
+        float co[3][16];
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float mx = ssim_rowpass16(v[0][i], wj), sx = ssim_rowpass16(v[1][i], wj);
+            const float pxy = ssim_rowpass16(v[2][i], wj);
+            const float my = ssim_rowpass16(v[3][i], wj), sy = ssim_rowpass16(v[4][i], wj);
+            const float num0 = mx * my * 2.0f;
+            const float den0 = mx * mx + my * my;
+            const float N0 = num0 + SSIM_C1, D0 = den0 + SSIM_C1;
+            const float N1 = (pxy * 2.0f - num0) + SSIM_C2;
+            const float D1 = ((sx + sy) - den0) + SSIM_C2;
+            const float r0 = 1.0f / D0, r1 = 1.0f / D1;
+            const float lum = N0 * r0, cs = N1 * r1;
+            acc = fmaf(lum, cs, acc);
+            if (GRAD) {
+                const float dl = (2.0f * my - lum * (2.0f * mx)) * r0;
+                const float dc = (cs * (2.0f * mx) - 2.0f * my) * r1;
+                co[0][i] = -swc * fmaf(cs, dl, lum * dc);
+                co[1][i] = swc * ((lum * cs) * r1);
+                co[2][i] = -swc * ((lum + lum) * r1);
+            }
+        }
+        part -= swc * acc;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) co[q][i] = ssim_rowpass16(co[q][i], wj);
+            }
+            float g3[3][16];
+            ssim_colpass16<3>(co, g3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                xp[i * 16] = fmaf(in[3][i], g3[2][i], fmaf(in[0][i] + in[0][i], g3[1][i], g3[0][i]));
+        }
     }
     return part;
 }
@@ -710,12 +842,20 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
     const int bh = a.bh, bw = a.bw;
     const float* s_Tr = s_ssim;
-    const float* s_Tc = s_ssim + bh * bh;
-    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N);
+    const float* s_Tc = s_ssim + bh * 11;
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
     float* s_Wa = s_X + C * N;
     float* s_Wb = s_Wa + 5 * N;
+    float wj[11];                                  // G == 16: this lane's row-pass weights T16[sub][sub + a - 5]
     if (SSIM) {
-        for (int i = threadIdx.x; i < bh * bh + bw * bw; i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+        if (G == 16) {
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                wj[q] = a.ssim_T[11 * 16 + sub * 11 + q];
+            }
+        } else {
+            for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+        }
     }
     float xc[D];                                   // coordinates of the lane's pixel i = 0 (hoisted axes: all its pixels)
 #pragma unroll
@@ -803,7 +943,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     }
                 }
                 wave_lds_sync();
-                acc[Lt::S_LOSS] = ssim_block<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, kc.sw, bh, bw, N, lane);
+                if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, true>(s_X, s_tgt, sub, wj, kc.sw);
+                else acc[Lt::S_LOSS] = ssim_block<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, kc.sw, bh, bw, N, lane);
                 for (int i = 0; i < pxl; ++i) {                 // sweep 2: forward again + backward with dL/dq
                     const int n = i * G + sub;
                     if (n < N) {
@@ -939,12 +1080,20 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     float* s_ssim = lds + T::off_ssim(N, has_lw, D);
     const int bh = a.bh, bw = a.bw;
     const float* s_Tr = s_ssim;
-    const float* s_Tc = s_ssim + bh * bh;
-    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N);
+    const float* s_Tc = s_ssim + bh * 11;
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
     float* s_Wa = s_X + C * N;
     float* s_Wb = s_Wa + 5 * N;
+    float wj[11];
     if (SSIM) {
-        for (int i = threadIdx.x; i < bh * bh + bw * bw; i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+        if (G == 16) {
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                wj[q] = a.ssim_T[11 * 16 + sub * 11 + q];
+            }
+        } else {
+            for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+        }
     }
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
@@ -1013,7 +1162,8 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
 
     if constexpr (SSIM) {                              // loss_pixel = 1 - SSIM (smoe.py:1006-1010)
         wave_lds_sync();
-        acc[Lt::S_LOSS] = ssim_block<C, false>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, N, lane);
+        if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, false>(s_X, const_cast<float*>(s_tgt), sub, wj, a.kc.sw);
+        else acc[Lt::S_LOSS] = ssim_block<C, false>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, N, lane);
     }
     float total[T::SPL];
     reduce_slots<D, C, K, G, WAVES, Layout<D, C, K>::NPAR>(acc, s_scratch, lane, total);
@@ -1127,18 +1277,13 @@ __global__ void best_kernel(BestArgs a) {
     if (threadIdx.x == 0) a.best_loss[b] = a.loss[b];
 }
 
-// host accumulation of smoe.py:1758-1761 -> three doubles (single workgroup, deterministic order)
-__global__ void reduce_scalars_kernel(ReduceArgs a) {
-    __shared__ double s[3][256];
-    double l = 0.0, e = 0.0, c = 0.0;
-    for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
-        if (a.loss) l += (double)a.loss[b] * (double)a.N;
-        if (a.sse) e += (double)a.sse[b];
-        if (a.active) c += (double)__popc(a.active[b]);
-    }
-    s[0][threadIdx.x] = l; s[1][threadIdx.x] = e; s[2][threadIdx.x] = c;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+// host accumulation of smoe.py:1758-1761 -> three doubles.  Two stages with a fixed assignment of blocks
+// to threads and a fixed tree order, so the result is deterministic: REDUCE_WGS workgroups write partial
+// sums, one workgroup combines them (a single workgroup over 65 536 blocks took 190 us of load latency).
+constexpr int REDUCE_WGS = 64;
+
+__device__ __forceinline__ void reduce3_tree(double (&s)[3][256], int n) {
+    for (int w = n / 2; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) {
             s[0][threadIdx.x] += s[0][threadIdx.x + w];
             s[1][threadIdx.x] += s[1][threadIdx.x + w];
@@ -1146,6 +1291,34 @@ __global__ void reduce_scalars_kernel(ReduceArgs a) {
         }
         __syncthreads();
     }
+}
+
+__global__ void reduce_scalars_kernel(ReduceArgs a) {
+    __shared__ double s[3][256];
+    double l = 0.0, e = 0.0, c = 0.0;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < a.B; b += REDUCE_WGS * 256) {
+        if (a.loss) l += (double)a.loss[b] * (double)a.N;
+        if (a.sse) e += (double)a.sse[b];
+        if (a.active) c += (double)__popc(a.active[b]);
+    }
+    s[0][threadIdx.x] = l; s[1][threadIdx.x] = e; s[2][threadIdx.x] = c;
+    __syncthreads();
+    reduce3_tree(s, 256);
+    if (threadIdx.x == 0) {
+        a.partials[blockIdx.x * 3 + 0] = s[0][0];
+        a.partials[blockIdx.x * 3 + 1] = s[1][0];
+        a.partials[blockIdx.x * 3 + 2] = s[2][0];
+    }
+}
+
+__global__ void reduce_partials_kernel(ReduceArgs a) {
+    __shared__ double s[3][256];
+    const bool in = (int)threadIdx.x < REDUCE_WGS;
+    s[0][threadIdx.x] = in ? a.partials[threadIdx.x * 3 + 0] : 0.0;
+    s[1][threadIdx.x] = in ? a.partials[threadIdx.x * 3 + 1] : 0.0;
+    s[2][threadIdx.x] = in ? a.partials[threadIdx.x * 3 + 2] : 0.0;
+    __syncthreads();
+    reduce3_tree(s, REDUCE_WGS);
     if (threadIdx.x == 0) { a.out[0] = s[0][0]; a.out[1] = s[1][0]; a.out[2] = s[2][0]; }
 }
 
@@ -1182,10 +1355,11 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
 // ssim_opt launches: instantiated for 2-d blocks on the one-block-per-wavefront tiling only
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
-    if constexpr (D == 2 && G == 64) {
+    if constexpr (D == 2) {
         using T = Tile<D, C, K, G, WAVES>;
-        auto kern = fit_kernel<D, C, K, G, WAVES, 0, true>;
-        int hl = 0;
+        if (G == 16 && (a.bh != 16 || a.bw != 16 || hoist < 1)) return hipErrorNotSupported;   // register path: 16x16 only
+        auto kern = fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
+        int hl = (G == 16) ? 1 : 0;
         if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
         const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1200,8 +1374,9 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
 
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
-    if constexpr (D == 2 && G == 64) {
+    if constexpr (D == 2) {
         using T = Tile<D, C, K, G, WAVES>;
+        if (G == 16 && (a.bh != 16 || a.bw != 16)) return hipErrorNotSupported;
         const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw);
         auto kern = forward_kernel<D, C, K, G, WAVES, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1219,7 +1394,8 @@ size_t lds_bytes(int N, bool has_lw) { return Tile<D, C, K, G, WAVES>::bytes(N, 
 
 template <int D, int C, int K, int G, int WAVES>
 size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw) {
-    return (D == 2 && G == 64) ? Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw) : (size_t)-1;
+    if (D != 2 || (G == 16 && (bh != 16 || bw != 16))) return (size_t)-1;
+    return Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw);
 }
 
 template <int D, int C, int K, int G, int WAVES>
@@ -1264,8 +1440,11 @@ hipError_t launch_best(const BestArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_reduce(const ReduceArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_scalars_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(reduce_scalars_kernel, dim3(REDUCE_WGS), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(REDUCE_WGS), 0, st, a);
     return hipGetLastError();
 }
+
+int reduce_partials_count() { return REDUCE_WGS * 3; }
 
 }  // namespace smoe

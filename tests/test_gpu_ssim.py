@@ -22,14 +22,28 @@ SSIM_SHAPES = [
 ]
 
 
+def _tilings(shape):
+    # 16x16 blocks: register / DPP stage on 16 lanes per block (default) and the LDS stage on a whole wavefront
+    return (16, 64) if tuple(shape) == (16, 16) else (0,)
+
+
 @pytest.mark.parametrize("shape,C,kpd,yuv", SSIM_SHAPES)
 def test_ssim_forward_loss(shape, C, kpd, yuv):
+    for tiling in _tilings(shape):
+        _forward_loss(shape, C, kpd, yuv, tiling)
+
+
+def _forward_loss(shape, C, kpd, yuv, tiling):
     B = 19
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 40 + C, pis_l1=0.2, u_l1=0.003, ssim_opt=True)
     active = np.ones((B, K), bool)
     eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.2, u_l1=0.003, ssim_opt=True)
     plain = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.2, u_l1=0.003)
-    assert "g64" in eng.fit_variant(B)
+    assert ("g16" if tuple(shape) == (16, 16) else "g64") in eng.fit_variant(B)
+    if tiling:
+        eng.set_tiling(tiling)
+        plain.set_tiling(tiling)
+        assert f"g{tiling}" in eng.fit_variant(B)
     dp = _to_dev(p)
     act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
     T = _planar(tgt)
@@ -59,10 +73,17 @@ def test_ssim_forward_loss(shape, C, kpd, yuv):
 
 @pytest.mark.parametrize("shape,C,kpd,yuv", SSIM_SHAPES)
 def test_ssim_one_step_gradients(shape, C, kpd, yuv):
+    for tiling in _tilings(shape):
+        _one_step_gradients(shape, C, kpd, yuv, tiling)
+
+
+def _one_step_gradients(shape, C, kpd, yuv, tiling):
     B = 21
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 300 + C, ssim_opt=True)
     active = np.ones((B, K), dtype=bool)
     eng = _engine(shape, C, K, use_yuv=yuv, ssim_opt=True)
+    if tiling:
+        eng.set_tiling(tiling)
     dp = _to_dev(p)
     act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
     T = _planar(tgt)
