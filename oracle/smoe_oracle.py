@@ -69,6 +69,12 @@ class OracleConfig:
     start_pis: Optional[int] = None       # smoe.py:264 (K0 of the l1 normaliser)
     only_y_gamma: bool = False            # smoe.py:725-729 (slopes only for channel 0)
     ssim_opt: bool = False                # smoe.py:929,980-1011: loss_pixel = 1 - SSIM (2-d blocks)
+    # fake-quantised parameters inside the graph (smoe.py:474-538); order of the 5-tuples: A, musX, nu_e, pis, gamma_e
+    quantization_mode: int = 0            # 0/1: none in the graph; 2: fixed ranges; 3: min/max of the model's kernels
+    quantize_pis: bool = False            # smoe.py:474 (the reference CLI passes True by default, smoe_test.py:304)
+    bit_depths: Tuple[int, ...] = (20, 18, 6, 10, 10)                 # smoe_test.py:302
+    lower_bounds: Tuple[float, ...] = (-2500, -.3, -5, 0, -32)        # smoe_test.py:306
+    upper_bounds: Tuple[float, ...] = (2500, 1.3, 5, 2, 32)           # smoe_test.py:308
 
     @property
     def dim(self) -> int:
@@ -193,6 +199,115 @@ def fake_quant01(y, precision, T):
 
 
 # --------------------------------------------------------------------------
+# fake-quantised parameters (smoe.py:474-538): TF fake_quant_with_min_max_{args,vars}
+# --------------------------------------------------------------------------
+def fq_nudge(mn, mx, bits, T):
+    """TF Nudge() (fake_quant_ops_functor.h): scale and the nudged range of [mn, mx] for ``bits`` bits, in T.
+    A zero-width range gives scale 0; callers treat min == max == 0 separately as TF does."""
+    qmin, qmax = T(0), T(2 ** bits - 1)
+    mn, mx = np.asarray(mn, dtype=T), np.asarray(mx, dtype=T)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = (mx - mn) / (qmax - qmin)
+        zp = qmin - mn / scale
+        rounded = np.sign(zp) * np.floor(np.abs(zp) + T(0.5))             # std::round: half away from zero
+        nzp = np.where(zp < qmin, qmin, np.where(zp > qmax, qmax, rounded)).astype(T)
+        return scale, ((qmin - nzp) * scale).astype(T), ((qmax - nzp) * scale).astype(T)
+
+
+def fq_apply(x, mn, mx, bits, T):
+    """fake_quant forward: floor((clamp(x) - nudged_min) * (1/scale) + 0.5) * scale + nudged_min and the
+    mask of elements inside the nudged range; min == max == 0 -> zeros (everything counts as inside)."""
+    scale, nmin, nmax = fq_nudge(mn, mx, bits, T)
+    zero = np.logical_and(np.asarray(mn) == 0, np.asarray(mx) == 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cl = np.minimum(np.maximum(x, nmin), nmax)
+        q = np.floor((cl - nmin) * (T(1) / scale) + T(0.5)) * scale + nmin
+    inside = np.logical_and(x >= nmin, x <= nmax)
+    return np.where(zero, T(0), q).astype(T), np.where(zero, True, inside)
+
+
+def _fq_minmax_vars(x, sel, bits, offset, T):
+    """Mode-3 tensor (smoe.py:497-530): range = min / max of x over the selected elements ``sel`` (bool, same
+    shape as x) of each block.  ``offset``: the ``fake_quant(x - min, 0, max - min) + min`` form (A_diagonal,
+    nu_e), else ``fake_quant(x, min, max)``.  Returns the q-tensor and the linear map of the backward pass
+    as masks: g -> g*between + tie_lo * sum(g*below) + tie_hi * sum(g*above) -- fake_quant_with_min_max_vars
+    sends what falls outside the NUDGED range to its min / max input, and reduce_min / reduce_max hand that
+    to the extreme elements, split equally over ties.  (Nudging keeps 0 exactly representable: an all-positive
+    range [lo, hi] becomes [0, hi - lo], so e.g. centres above hi - lo are clamped -- restated as is.)"""
+    ax = tuple(range(1, x.ndim))
+    lo = np.where(sel, x, np.inf).min(axis=ax, keepdims=True)
+    hi = np.where(sel, x, -np.inf).max(axis=ax, keepdims=True)
+    none = ~sel.any(axis=ax, keepdims=True)
+    lo = np.where(none, 0, lo).astype(T)
+    hi = np.where(none, 0, hi).astype(T)
+    if offset:
+        v, rmin, rmax, back = x - lo, np.zeros_like(lo), hi - lo, lo
+    else:
+        v, rmin, rmax, back = x, lo, hi, np.zeros_like(lo)
+    scale, nmin, nmax = fq_nudge(rmin, rmax, bits, T)
+    zero = np.logical_and(rmin == 0, rmax == 0)              # TF: zeros forward, identity backward
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cl = np.minimum(np.maximum(v, nmin), nmax)
+        q = np.floor((cl - nmin) * (T(1) / scale) + T(0.5)) * scale + nmin
+    q = (np.where(zero, T(0), q) + back).astype(T)
+    below = np.logical_and(~zero, v < nmin)
+    above = np.logical_and(~zero, v > nmax)
+    tie_lo = np.logical_and(sel, x == lo).astype(T)
+    tie_hi = np.logical_and(sel, x == hi).astype(T)
+    tie_lo = tie_lo / np.maximum(tie_lo.sum(axis=ax, keepdims=True), 1)
+    tie_hi = tie_hi / np.maximum(tie_hi.sum(axis=ax, keepdims=True), 1)
+    return q, {"between": ~(below | above), "below": below, "above": above, "tie_lo": tie_lo, "tie_hi": tie_hi}
+
+
+def quantize_graph_params(p, cfg: OracleConfig, T):
+    """The q-tensors the graph is built on (smoe.py:474-538) and, per tensor, the backward map of the
+    fake-quant ops (see ``route_quant_grads``).  Mode 3 ranges are the min/max over the kernels with
+    qpis > 0 (pis_mask, NOT the kernel list)."""
+    lb, ub, bd = cfg.lower_bounds, cfg.upper_bounds, cfg.bit_depths
+    q = {k: p[k].astype(T) for k in PARAM_NAMES}
+    back = {}
+    mode = cfg.quantization_mode
+    if mode >= 2 or cfg.quantize_pis:
+        q["pis"], inside = fq_apply(q["pis"], T(lb[3]), T(ub[3]), bd[3], T)
+        back["pis"] = {"between": inside}
+    keep = q["pis"] > 0
+    if mode == 2:
+        for name, i in (("A_diagonal", 0), ("A_corr", 0), ("musX", 1), ("nu_e", 2), ("gamma_e", 4)):
+            q[name], inside = fq_apply(q[name], T(lb[i]), T(ub[i]), bd[i], T)
+            back[name] = {"between": inside}
+    elif mode == 3:
+        def sel_all(x):
+            return np.broadcast_to(keep.reshape(keep.shape + (1,) * (x.ndim - 2)), x.shape)
+        d = q["A_diagonal"].shape[-1]
+        diag_sel = np.logical_and(sel_all(q["A_diagonal"]), np.eye(d, dtype=bool))
+        q["A_diagonal"], back["A_diagonal"] = _fq_minmax_vars(q["A_diagonal"], diag_sel, bd[0], True, T)
+        q["A_corr"], back["A_corr"] = _fq_minmax_vars(q["A_corr"], sel_all(q["A_corr"]), bd[0], False, T)
+        if cfg.train_musx:
+            q["musX"], back["musX"] = _fq_minmax_vars(q["musX"], sel_all(q["musX"]), bd[1], False, T)
+        q["nu_e"], back["nu_e"] = _fq_minmax_vars(q["nu_e"], sel_all(q["nu_e"]), bd[2], True, T)
+        q["gamma_e"], back["gamma_e"] = _fq_minmax_vars(q["gamma_e"], sel_all(q["gamma_e"]), bd[4], False, T)
+    return q, back, keep
+
+
+def route_quant_grads(grads, back, T):
+    """Gradients w.r.t. the q-tensors -> gradients w.r.t. the variables (registered gradients of
+    fake_quant_with_min_max_args / _vars composed with reduce_min / reduce_max)."""
+    out = {}
+    for k, g in grads.items():
+        b = back.get(k)
+        if b is None:
+            out[k] = g
+            continue
+        r = np.where(b["between"], g, T(0))
+        if "below" in b:
+            ax = tuple(range(1, g.ndim))
+            r = r + b["tie_lo"] * np.sum(np.where(b["below"], g, T(0)), axis=ax, keepdims=True) \
+                  + b["tie_hi"] * np.sum(np.where(b["above"], g, T(0)), axis=ax, keepdims=True)
+        out[k] = r.astype(T)
+    return out
+
+
+# --------------------------------------------------------------------------
 # SSIM loss (smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d blocks
 # --------------------------------------------------------------------------
 SSIM_SIZE, SSIM_SIGMA, SSIM_PAD = 11, 1.5, 5                  # image_ops_impl.py:180-181; smoe.py:994
@@ -290,6 +405,9 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     if x.ndim == 2:
         x = np.broadcast_to(x[None], (B,) + x.shape)        # (B,N,d)
     t = target.astype(T)
+    graph_quant = cfg.quantization_mode >= 2 or cfg.quantize_pis
+    if graph_quant:                                          # smoe.py:474-538: the graph sees fake-quantised variables
+        p, qback, _ = quantize_graph_params(p, cfg, T)
     pis = p["pis"].astype(T)
     mu = p["musX"].astype(T)
     nu = p["nu_e"].astype(T)
@@ -404,6 +522,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
         g_gam[..., 1:] = T(0)
     out["grads"] = {"pis": g_pi, "musX": g_mu, "A_diagonal": g_Adiag, "A_corr": g_Acorr,
                     "gamma_e": g_gam, "nu_e": g_nu}
+    if graph_quant:                                          # back through the fake-quant ops
+        out["grads"] = route_quant_grads(out["grads"], qback, T)
     return out
 
 
@@ -466,6 +586,8 @@ def readmit(p, active, cfg: OracleConfig, dtype=np.float32):
     axes = axis_coords(cfg.block_shape)
     tt = [(ax.min(), ax.max(), (ax.min() + ax.max()) / 2) for ax in axes]
     probes = np.array(list(itertools.product(*tt))).astype(np.float32).astype(T)   # (3^d, d)
+    if cfg.quantization_mode >= 2 or cfg.quantize_pis:      # maha_dist_ind is part of the same graph (smoe.py:806)
+        p = quantize_graph_params(p, cfg, T)[0]
     A = _steering(p, T)
     mu = p["musX"].astype(T)
     r = probes[None, None, :, :] - mu[:, :, None, :]

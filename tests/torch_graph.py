@@ -29,6 +29,80 @@ class _FakeQuant01(torch.autograd.Function):
         return g * inside.to(g.dtype), None
 
 
+def _nudge(mn, mx, bits):
+    """TF fake_quant Nudge(): scale, nudged_min, nudged_max for the range [mn, mx] (tensors or floats)."""
+    qmin, qmax = 0.0, float(2 ** bits - 1)
+    scale = (mx - mn) / (qmax - qmin)
+    zp = qmin - mn / scale
+    nzp = torch.where(zp < qmin, torch.full_like(zp, qmin),
+                      torch.where(zp > qmax, torch.full_like(zp, qmax), torch.sign(zp) * torch.floor(zp.abs() + 0.5)))
+    return scale, (qmin - nzp) * scale, (qmax - nzp) * scale
+
+
+class _FakeQuantVars(torch.autograd.Function):
+    """tf.quantization.fake_quant_with_min_max_vars(x, min, max, num_bits) and its registered gradient: the
+    input gradient passes inside [nudged_min, nudged_max]; what falls below goes to ``min``, above to ``max``.
+    min == max == 0 gives zeros (fake_quant_ops_functor.h)."""
+
+    @staticmethod
+    def forward(ctx, x, mn, mx, bits):
+        if float(mn) == 0.0 and float(mx) == 0.0:
+            ctx.zero = True
+            ctx.save_for_backward(x)
+            return torch.zeros_like(x)
+        ctx.zero = False
+        scale, nmin, nmax = _nudge(mn.detach(), mx.detach(), bits)
+        ctx.save_for_backward(x, nmin, nmax)
+        cl = torch.minimum(torch.maximum(x, nmin), nmax)
+        return torch.floor((cl - nmin) * (1.0 / scale) + 0.5) * scale + nmin
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.zero:                      # "If min and max are both zero, we propagate everything to inputs."
+            return g, torch.zeros(()), torch.zeros(()), None
+        x, nmin, nmax = ctx.saved_tensors
+        below, above = x < nmin, x > nmax
+        between = ~(below | above)
+        return g * between.to(g.dtype), (g * below.to(g.dtype)).sum(), (g * above.to(g.dtype)).sum(), None
+
+
+def _fake_quant_args(x, mn, mx, bits):
+    """fake_quant_with_min_max_args: constant range (no gradient to it)."""
+    return _FakeQuantVars.apply(x, torch.tensor(float(mn), dtype=x.dtype), torch.tensor(float(mx), dtype=x.dtype), bits)
+
+
+def quantize_graph_params(params, *, quantization_mode, quantize_pis, bit_depths, lower_bounds, upper_bounds,
+                          train_musx=True):
+    """smoe.py:474-538: the fake-quantised views of the variables the graph is built on.
+    bit_depths / bounds order: A, musX, nu_e, pis, gamma_e (smoe_test.py:302-309)."""
+    pis_v, musX_v = params["pis"], params["musX"]
+    Ad_v, Ac_v, gam_v, nu_v = params["A_diagonal"], params["A_corr"], params["gamma_e"], params["nu_e"]
+    lb, ub, bd = lower_bounds, upper_bounds, bit_depths
+    if quantization_mode >= 2 or quantize_pis:
+        qpis = _fake_quant_args(pis_v, lb[3], ub[3], bd[3])
+    else:
+        qpis = pis_v
+    pis_mask = qpis > 0
+    if quantization_mode == 2:
+        qAd = _fake_quant_args(Ad_v, lb[0], ub[0], bd[0])
+        qAc = _fake_quant_args(Ac_v, lb[0], ub[0], bd[0])
+        qmu = _fake_quant_args(musX_v, lb[1], ub[1], bd[1])
+        qnu = _fake_quant_args(nu_v, lb[2], ub[2], bd[2])
+        qga = _fake_quant_args(gam_v, lb[4], ub[4], bd[4])
+    elif quantization_mode == 3:
+        dg = torch.diagonal(Ad_v[pis_mask], dim1=-2, dim2=-1)
+        mn, mx = dg.min(), dg.max()
+        qAd = _FakeQuantVars.apply(Ad_v - mn, torch.zeros_like(mn), mx - mn, bd[0]) + mn
+        qAc = _FakeQuantVars.apply(Ac_v, Ac_v[pis_mask].min(), Ac_v[pis_mask].max(), bd[0])
+        qmu = _FakeQuantVars.apply(musX_v, musX_v[pis_mask].min(), musX_v[pis_mask].max(), bd[1]) if train_musx else musX_v
+        mn, mx = nu_v[pis_mask].min(), nu_v[pis_mask].max()
+        qnu = _FakeQuantVars.apply(nu_v - mn, torch.zeros_like(mn), mx - mn, bd[2]) + mn
+        qga = _FakeQuantVars.apply(gam_v, gam_v[pis_mask].min(), gam_v[pis_mask].max(), bd[4])
+    else:
+        qAd, qAc, qmu, qnu, qga = Ad_v, Ac_v, musX_v, nu_v, gam_v
+    return {"pis": qpis, "musX": qmu, "A_diagonal": qAd, "A_corr": qAc, "gamma_e": qga, "nu_e": qnu}, pis_mask
+
+
 def custom_ssim_2d(img1, img2):
     """ops/image_ops_impl.py:77-233 for (H,W,C) inputs with max_val = 1: 11x11 Gaussian (sigma 1.5, built with
     a softmax), VALID depthwise correlation, mean of luminance * contrast-structure per channel."""
@@ -64,13 +138,18 @@ def _symmetric_pad(img, pad):
 
 def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0.5,
                    use_determinant=True, use_yuv=False, train_gammas=True,
-                   pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None):
+                   pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None,
+                   quantization_mode=0, quantize_pis=False, bit_depths=(20, 18, 6, 10, 10),
+                   lower_bounds=(-2500, -.3, -5, 0, -32), upper_bounds=(2500, 1.3, 5, 2, 32), train_musx=True):
     """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
     with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
     Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
-    pis_v, musX_v = params["pis"], params["musX"]
-    Ad_v, Ac_v = params["A_diagonal"], params["A_corr"]
-    gam_v, nu_v = params["gamma_e"], params["nu_e"]
+    qp, pis_mask = quantize_graph_params(params, quantization_mode=quantization_mode, quantize_pis=quantize_pis,
+                                         bit_depths=bit_depths, lower_bounds=lower_bounds, upper_bounds=upper_bounds,
+                                         train_musx=train_musx)
+    pis_v, musX_v = qp["pis"], qp["musX"]
+    Ad_v, Ac_v = qp["A_diagonal"], qp["A_corr"]
+    gam_v, nu_v = qp["gamma_e"], qp["nu_e"]
     K, d = musX_v.shape
     C = nu_v.shape[1]
     N = coords.shape[0]
@@ -78,7 +157,7 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
     # smoe.py:732-733  band_part(A_diagonal,0,0) + band_part(set_diag(A_corr,0),-1,0)
     A = torch.diag_embed(torch.diagonal(Ad_v, dim1=-2, dim2=-1)) + torch.tril(Ac_v, diagonal=-1)
     # smoe.py:480,738-753
-    bool_mask = kernel_list & (pis_v > 0)
+    bool_mask = kernel_list & pis_mask
     indices = torch.arange(K)[bool_mask]
     musX, nu_e, gamma_e, A, pis = musX_v[bool_mask], nu_v[bool_mask], gam_v[bool_mask], A[bool_mask], pis_v[bool_mask]
     # smoe.py:777-782,796
