@@ -44,7 +44,7 @@ def cpu_baseline(block_shape, C, kpd, blocks_np, n_iters, budget_s):
     from oracle import c_oracle as co
     from oracle import smoe_oracle as o
     K = int(np.prod(kpd))
-    cfg = o.OracleConfig(block_shape=tuple(block_shape), channels=C, kernels=K)
+    cfg = o.OracleConfig(block_shape=tuple(block_shape), channels=C, kernels=K, quantize_pis=True)   # CLI default -qp
     threads = min(os.cpu_count() or 1, 64)
     N = int(np.prod(block_shape))
     coords = np.ascontiguousarray(o.block_coords(block_shape).T)
@@ -116,7 +116,8 @@ def main():
     # ---- synthetic inputs, resident in HBM before timing ------------------------------
     blocks_np = blk.synthetic_blocks(B, shape, C, 20260002 + rank)
     params_np = blk.init_block_params(blocks_np, kpd)
-    eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv))
+    # CLI defaults (smoe_test.py:262-352): -qp/--quantize_pis defaults to True, so the graph fake-quantises the pis
+    eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv, quantize_pis=True))
     if args.tiling:
         eng.set_tiling(args.tiling)
     dev = eng.device
@@ -190,7 +191,7 @@ def main():
     single = None
     if rank == 0 and not args.no_extras and shape == (16, 16) and C == 1 and B >= 1024:
         Bs = 1024
-        eng1 = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv))
+        eng1 = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv, quantize_pis=True))
         p1 = {k: torch.from_numpy(v[:Bs].copy()).to(dev) for k, v in params_np.items()}
         st1 = eng1.new_adam_state(p1)
         a1 = torch.full((Bs,), (1 << K) - 1, dtype=torch.int32, device=dev)

@@ -73,6 +73,17 @@ typedef struct smoe_config {
                                    pixels): custom_ssim on SYMMETRIC-padded blocks, 11x11 Gaussian, channel
                                    weights 6/8,1/8,1/8 (yuv) or the mean; loss_w is ignored as in the reference
                                    smoe.py:929,980-1011, ops/image_ops_impl.py:77-233                     */
+    /* Fake-quantised variables inside the graph (smoe.py:474-538): forward, gradients and update_kernel_list see
+     * tf.quantization.fake_quant_with_min_max_{args,vars} of the variables; Adam keeps updating the raw ones.
+     * 5-tuples in the reference's order A, musX, nu_e, pis, gamma_e (smoe_test.py:302-309). */
+    int32_t quantization_mode;  /* 0/1: nothing in the graph; 2: fixed ranges lower/upper_bounds; 3: min/max over the
+                                   block's kernels with qpis > 0 (A_diagonal and nu_e as x - min)   smoe.py:482-530.
+                                   Mode 3 assumes A_corr is zero on and above its diagonal (as the reference keeps it) */
+    int32_t quantize_pis;       /* pis through [lower_bounds[3], upper_bounds[3]] (implied by mode >= 2). NOTE: the
+                                   reference CLI passes True by default (smoe_test.py:304, smoe.py:474)           */
+    int32_t bit_depths[5];
+    float   lower_bounds[5];
+    float   upper_bounds[5];
 } smoe_config;
 
 /* Parameter set in the reference's get_params() layout (smoe.py:1795-1800) with a
@@ -189,6 +200,11 @@ typedef struct smoe_shared_config {
     int32_t start_pis;
     int32_t only_y_gamma;
     int32_t overlap;                    /* overlap_of_batches (smoe.py:244), pixels per side */
+    int32_t quantization_mode;          /* as smoe_config; 0/1/2 (mode 3 is not built for this mode)  smoe.py:474-496 */
+    int32_t quantize_pis;
+    int32_t bit_depths[5];
+    float   lower_bounds[5];
+    float   upper_bounds[5];
 } smoe_shared_config;
 
 typedef struct smoe_shared_context* smoe_shared_handle;

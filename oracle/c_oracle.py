@@ -19,7 +19,8 @@ class OracleCfg(C.Structure):
                 ("train_musx", C.c_int32), ("lr_expert", C.c_float), ("lr_pis", C.c_float),
                 ("lr_steer", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
                 ("grad_clip", C.c_float), ("pis_l1", C.c_float), ("u_l1", C.c_float), ("start_pis", C.c_int32),
-                ("only_y_gamma", C.c_int32)]
+                ("only_y_gamma", C.c_int32), ("quantize_pis", C.c_int32), ("pis_bits", C.c_int32),
+                ("pis_lb", C.c_float), ("pis_ub", C.c_float)]
 
 
 _lib = None
@@ -48,6 +49,12 @@ def _cfg(cfg):
     c.grad_clip = cfg.grad_clip or 0.0
     c.pis_l1, c.u_l1, c.start_pis = cfg.pis_l1, cfg.u_l1, cfg.k0
     c.only_y_gamma = int(getattr(cfg, 'only_y_gamma', False))
+    if getattr(cfg, "quantization_mode", 0) >= 2:
+        raise NotImplementedError("the plain-C restatement has quantize_pis only; modes 2/3 live in smoe_oracle.py")
+    c.quantize_pis = int(getattr(cfg, "quantize_pis", False))
+    c.pis_bits = int(cfg.bit_depths[3]) if c.quantize_pis else 0
+    c.pis_lb = float(cfg.lower_bounds[3]) if c.quantize_pis else 0.0
+    c.pis_ub = float(cfg.upper_bounds[3]) if c.quantize_pis else 0.0
     return c
 
 

@@ -37,6 +37,9 @@ typedef struct oracle_cfg {
     float pis_l1, u_l1;
     int32_t start_pis;
     int32_t only_y_gamma;       /* smoe.py:725-729 */
+    int32_t quantize_pis;       /* smoe.py:474-478: pis go through fake_quant_with_min_max_args(lb, ub, bits) */
+    int32_t pis_bits;
+    float pis_lb, pis_ub;
 } oracle_cfg;
 
 typedef struct grads_t {
@@ -46,7 +49,7 @@ typedef struct grads_t {
 /* One pass over one block (smoe.py:732-937,1012-1053).  Returns loss; fills sse, the new
  * influence mask, optionally recon [C][N] and the analytic gradients. */
 static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, const float* tgt /*[C][N]*/,
-                        const float* lw /*[N] or NULL*/, const float* pis, const float* mu, const float* Ad,
+                        const float* lw /*[N] or NULL*/, const float* pis_var, const float* mu, const float* Ad,
                         const float* Ac, const float* ga, const float* nu, uint32_t active,
                         float* sse_out, uint32_t* active_new, float* recon, grads_t* g) {
     const int D = c->dim, C = c->channels, K = c->kernels, N = c->pixels;
@@ -59,6 +62,24 @@ static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, con
     const int y_only = c->only_y_gamma && c->use_yuv && c->train_gammas; /* smoe.py:725 */
     float A[MAXK][MAXD][MAXD], coef[MAXK];
     int act[MAXK];
+    /* quantize_pis: TF Nudge() + fake quant in fp32; the gradient passes inside the nudged range only */
+    float qpis[MAXK];
+    int pis_ste[MAXK];
+    for (int k = 0; k < K; ++k) { qpis[k] = pis_var[k]; pis_ste[k] = 1; }
+    if (c->quantize_pis) {
+        const float qmax = (float)((1u << c->pis_bits) - 1u);
+        const float sc = (c->pis_ub - c->pis_lb) / qmax;
+        const float zp = 0.0f - c->pis_lb / sc;
+        const float nzp = (zp < 0.0f) ? 0.0f : ((zp > qmax) ? qmax : roundf(zp));
+        const float nmin = (0.0f - nzp) * sc, nmax = (qmax - nzp) * sc, inv = 1.0f / sc;
+        for (int k = 0; k < K; ++k) {
+            const float x = pis_var[k];
+            const float cl = fminf(fmaxf(x, nmin), nmax);
+            qpis[k] = floorf((cl - nmin) * inv + 0.5f) * sc + nmin;
+            pis_ste[k] = (x >= nmin) && (x <= nmax);
+        }
+    }
+    const float* pis = qpis;
     float cw[MAXC];
     for (int ch = 0; ch < C; ++ch)
         cw[ch] = c->use_yuv ? (float)(((ch == 0) ? 6.0 / 8.0 : 1.0 / 8.0) / (double)N) : (float)(1.0 / ((double)N * C));
@@ -158,7 +179,7 @@ static float block_pass(const oracle_cfg* c, const float* coords /*[D][N]*/, con
         if (c->u_l1 != 0.0f)
             for (int l = 0; l < D; ++l) loss += c->u_l1 * A[k][l][l];  /* smoe.py:1044 */
         if (g) {
-            g->pis[k] = su[k] / pis[k] + c->pis_l1 / k0;
+            g->pis[k] = pis_ste[k] ? su[k] / pis[k] + c->pis_l1 / k0 : 0.0f;
             for (int l = 0; l < D; ++l) {
                 if (c->use_determinant) g->A[k][l][l] += su[k] / A[k][l][l];
                 g->A[k][l][l] += c->u_l1;

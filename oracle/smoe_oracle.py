@@ -731,6 +731,8 @@ def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):   # c
     NB, _, d = coords.shape
     mins, maxs = coords.min(axis=1).astype(np.float64), coords.max(axis=1).astype(np.float64)
     tt = np.stack([mins, maxs, (mins + maxs) / 2], axis=-1)                       # (NB,d,3)
+    if cfg.quantization_mode >= 2 or cfg.quantize_pis:      # the probe test is part of the fake-quantised graph
+        p = quantize_graph_params(p, cfg, T)[0]
     A = _steering(p, T)[0]
     mu = p["musX"].astype(T)[0]
     out = lists.copy()

@@ -79,6 +79,41 @@ void ssim_axis_table(int b, float* out) {
         }
 }
 
+// fake-quantised variables (smoe.py:474-538): nudged constants of the fixed ranges, TF Nudge() in fp32
+void fill_quant_consts(smoe::KernelConsts& kc, int mode, int quantize_pis, int train_musx, const int32_t* bits,
+                       const float* lb, const float* ub) {
+    kc.qmode = (mode >= 2) ? mode : 0;
+    kc.qpis = (mode >= 2 || quantize_pis) ? 1 : 0;
+    kc.q_musx = train_musx ? 1 : 0;
+    for (int g = 0; g < 5; ++g) {
+        kc.q_nmin[g] = kc.q_nmax[g] = kc.q_scale[g] = kc.q_inv[g] = 0.0f;
+        kc.q_levels[g] = 1.0f;
+        if (!(kc.qmode || (g == 3 && kc.qpis))) continue;
+        const float levels = (float)(std::ldexp(1.0, bits[g]) - 1.0);
+        const float mn = lb[g], mx = ub[g];
+        const float sc = (mx - mn) / levels;
+        const float zp = 0.0f - mn / sc;
+        const float nzp = (zp < 0.0f) ? 0.0f : ((zp > levels) ? levels : std::round(zp));
+        kc.q_levels[g] = levels;
+        kc.q_scale[g] = sc;
+        kc.q_inv[g] = 1.0f / sc;
+        kc.q_nmin[g] = (0.0f - nzp) * sc;
+        kc.q_nmax[g] = (levels - nzp) * sc;
+    }
+}
+
+int check_quant_config(int mode, int quantize_pis, const int32_t* bits, const float* lb, const float* ub, const char** msg) {
+    if (mode < 0 || mode > 3) { *msg = "quantization_mode must be 0..3"; return SMOE_ERR_INVALID; }
+    if (mode >= 2 || quantize_pis) {
+        for (int g = 0; g < 5; ++g) {
+            if (mode < 2 && g != 3) continue;
+            if (bits[g] < 2 || bits[g] > 24) { *msg = "bit_depths must be 2..24 (fp32 lattice)"; return SMOE_ERR_INVALID; }
+            if ((mode != 3 || g == 3) && !(lb[g] < ub[g])) { *msg = "lower_bounds must be below upper_bounds"; return SMOE_ERR_INVALID; }
+        }
+    }
+    return SMOE_OK;
+}
+
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
@@ -136,6 +171,14 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         N *= cfg->block_shape[l];
     }
     if (N > 8192) return fail(SMOE_ERR_INVALID, "smoe_create: more than 8192 pixels per block");
+    {
+        const char* qmsg = nullptr;
+        const int qrc = check_quant_config(cfg->quantization_mode, cfg->quantize_pis, cfg->bit_depths, cfg->lower_bounds,
+                                           cfg->upper_bounds, &qmsg);
+        if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_create: ") + qmsg);
+    }
+    if (cfg->ssim_opt && cfg->quantization_mode >= 2)
+        return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt together with quantization_mode 2/3 is not instantiated");
     if (cfg->ssim_opt) {
         // the reference pads every axis SYMMETRIC by 5 (smoe.py:993-1003), which TF only accepts for axes of
         // at least 5 samples; 3-d blocks would need an 11^3 window over a padded time axis and are not built
@@ -232,6 +275,8 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         const double w = cfg->use_yuv ? ((c == 0) ? 6.0 / 8.0 : 1.0 / 8.0) : 1.0 / (double)C;
         kc.sw[c] = (float)(w / (double)N);
     }
+    fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
+                      cfg->lower_bounds, cfg->upper_bounds);
     if (cfg->ssim_opt && !find_variant(h, 1, false)) {
         smoe_destroy(h);
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt planes of this block size do not fit in LDS");
@@ -299,6 +344,7 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.kc = h->kc;
     a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1];
     if (h->cfg.ssim_opt) HIP_TRY(v->fwd_ssim(a, (hipStream_t)stream), "smoe_forward (ssim) launch");
+    else if (h->kc.qmode) HIP_TRY(v->fwd_quant(a, (hipStream_t)stream), "smoe_forward (quantised) launch");
     else HIP_TRY(v->fwd(a, (hipStream_t)stream), "smoe_forward launch");
     return SMOE_OK;
 }
@@ -338,6 +384,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     }
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1];
     if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
+    else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
     else HIP_TRY(v->fit(a, hoist, (hipStream_t)stream), "smoe_fit launch");
     // TF multiplies the beta powers after every apply (fp32 running product)
     for (int i = 0; i < n_iters; ++i) {
@@ -357,6 +404,12 @@ int smoe_update_kernel_list(smoe_handle h, int32_t num_blocks, const smoe_params
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::ReadmitArgs a;
     a.p = *p; a.active = active; a.probes = h->d_probes; a.B = num_blocks; a.K = h->cfg.kernels;
+    if (h->kc.qmode || h->kc.qpis) {                 // the probe test runs on the fake-quantised variables
+        const smoe::Variant* v = find_variant(h, num_blocks, false);
+        if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_update_kernel_list: no kernel variant");
+        HIP_TRY(v->readmit_quant(a, h->kc, (hipStream_t)stream), "smoe_update_kernel_list (quantised) launch");
+        return SMOE_OK;
+    }
     HIP_TRY(smoe::launch_readmit(a, h->cfg.dim, (hipStream_t)stream), "smoe_update_kernel_list launch");
     return SMOE_OK;
 }
@@ -448,6 +501,14 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         NB *= cfg->image_shape[l] / cfg->batch_shape[l];
     }
     if (cfg->overlap < 0 || cfg->overlap > 64) return fail(SMOE_ERR_INVALID, "smoe_shared_create: overlap must be 0..64");
+    {
+        const char* qmsg = nullptr;
+        const int qrc = check_quant_config(cfg->quantization_mode, cfg->quantize_pis, cfg->bit_depths, cfg->lower_bounds,
+                                           cfg->upper_bounds, &qmsg);
+        if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_shared_create: ") + qmsg);
+        if (cfg->quantization_mode == 3)
+            return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: quantization_mode 3 (image-wide min/max ranges) is not built for the shared-kernel mode");
+    }
     if (!smoe::shared_supported(cfg->dim, cfg->channels, (int)Nb))
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: batch too large (<= 2048 pixels for 1 channel, <= 1024 for 3)");
     const int KW = (cfg->kernels + 31) / 32;
@@ -533,6 +594,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     kc.use_det = cfg->use_determinant ? 1 : 0;
     kc.train_gammas = cfg->train_gammas ? 1 : 0;
     kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;
+    fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
+                      cfg->lower_bounds, cfg->upper_bounds);
     *out = h;
     return SMOE_OK;
 }
@@ -602,6 +665,7 @@ int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, 
     a.clip = c.grad_clip;
     a.lr_expert = c.lr_expert; a.lr_pis = c.lr_pis; a.lr_steer = c.lr_steer;
     a.train_pis = c.train_pis; a.train_musx = c.train_musx; a.train_gammas = c.train_gammas; a.use_det = c.use_determinant; a.only_y_gamma = h->kc.only_y_gamma;
+    a.kc = h->kc;
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
     a.reg_u = c.u_l1;
     HIP_TRY(smoe::launch_shared_adam(a, c.dim, c.channels, (hipStream_t)stream), "smoe_shared_apply launch");
@@ -634,7 +698,7 @@ int smoe_shared_update_kernel_list(smoe_shared_handle h, int32_t first_batch, in
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::SharedReadmitArgs a;
     a.p = *p; a.lists = lists; a.probes = h->d_probes + (size_t)first_batch * h->cfg.dim * 3;
-    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW;
+    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW; a.kc = h->kc;
     HIP_TRY(smoe::launch_shared_readmit(a, h->cfg.dim, (hipStream_t)stream), "smoe_shared_update_kernel_list launch");
     return SMOE_OK;
 }

@@ -25,6 +25,12 @@ struct KernelConsts {
     int train_gammas;   // smoe.py:841
     int only_y_gamma;   // gamma_mask: slopes only for channel 0 (smoe.py:725-729)
     float sw[SMOE_MAX_CHANNELS];  // ssim_opt: SSIM channel weight / window count (smoe.py:1006-1009)
+    // fake-quantised parameters inside the graph (smoe.py:474-538).  Group order: 0 A, 1 musX, 2 nu_e, 3 pis, 4 gamma_e
+    int qmode;          // 0 none, 2 fixed ranges (lower/upper_bounds), 3 min/max over the model's kernels
+    int qpis;           // pis through the fixed range (mode >= 2 or quantize_pis)
+    int q_musx;         // mode 3 quantises musX only when it is trained (smoe.py:515)
+    float q_nmin[5], q_nmax[5], q_scale[5], q_inv[5];   // nudged fixed ranges (TF Nudge(), fp32)
+    float q_levels[5];  // 2^bits - 1
 };
 
 struct FitArgs {
@@ -100,6 +106,9 @@ struct Variant {
     hipError_t (*fit_ssim)(const FitArgs&, int hoist_level, hipStream_t);   // ssim_opt (D == 2, G == 64)
     hipError_t (*fwd_ssim)(const FwdArgs&, hipStream_t);
     size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw);
+    hipError_t (*readmit_quant)(const ReadmitArgs&, const KernelConsts&, hipStream_t);   // fake-quantised graph
+    hipError_t (*fit_quant)(const FitArgs&, int hoist_level, hipStream_t);               // quantization_mode 2 / 3
+    hipError_t (*fwd_quant)(const FwdArgs&, hipStream_t);
 };
 
 // ---- shared-kernel image mode (smoe_shared.hip) ----------------------------------------------
@@ -134,6 +143,7 @@ struct SharedAdamArgs {
     float lr_expert, lr_pis, lr_steer;
     int train_pis, train_musx, train_gammas, use_det, only_y_gamma;
     float reg_pi, reg_u;
+    KernelConsts kc;          // fixed-range fake quant of the variables (quantize_pis, quantization_mode 2)
 };
 
 struct SharedReadmitArgs {
@@ -141,6 +151,7 @@ struct SharedReadmitArgs {
     uint32_t* lists;          // [nb][KW]
     const float* probes;      // [nb][D][3]
     int NB, K, KW;
+    KernelConsts kc;
 };
 
 size_t shared_lds_bytes(int D, int C, int K, int KW);

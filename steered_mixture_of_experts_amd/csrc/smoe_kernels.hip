@@ -173,6 +173,209 @@ struct BlockRegs {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Fake-quantised parameters (quantize_pis, quantization_mode 2 / 3; smoe.py:474-538): TF
+// fake_quant_with_min_max_{args,vars}.  Every lane holds all K kernels of its block, so the ranges of
+// mode 3 (min / max over the kernels with qpis > 0) need no cross-lane step.
+// ---------------------------------------------------------------------------
+struct FqRange {
+    float nmin, nmax, scale, inv, back;   // nudged range, step, 1/step, offset added back (x - min forms)
+    bool zero;                            // min == max == 0: TF outputs zeros and passes the whole gradient
+};
+
+__device__ __forceinline__ FqRange fq_fixed(const KernelConsts& kc, int g) {
+    FqRange r;
+    r.nmin = kc.q_nmin[g]; r.nmax = kc.q_nmax[g]; r.scale = kc.q_scale[g]; r.inv = kc.q_inv[g];
+    r.back = 0.0f; r.zero = false;
+    return r;
+}
+
+// TF Nudge() on [rmin, rmax] with levels = 2^bits - 1 (fake_quant_ops_functor.h), fp32 as on the device there
+__device__ __forceinline__ FqRange fq_vars(float lo, float hi, float levels, bool offset) {
+    FqRange r;
+    const float rmin = offset ? 0.0f : lo;
+    const float rmax = offset ? hi - lo : hi;
+    r.back = offset ? lo : 0.0f;
+    r.zero = (rmin == 0.0f) && (rmax == 0.0f);
+    r.scale = (rmax - rmin) / levels;
+    const float zp = 0.0f - rmin / r.scale;
+    const float nzp = (zp < 0.0f) ? 0.0f : ((zp > levels) ? levels : roundf(zp));
+    r.nmin = (0.0f - nzp) * r.scale;
+    r.nmax = (levels - nzp) * r.scale;
+    r.inv = 1.0f / r.scale;
+    return r;
+}
+
+__device__ __forceinline__ float fq_val(float x, const FqRange& r) {
+    const float v = x - r.back;
+    const float cl = fminf(fmaxf(v, r.nmin), r.nmax);
+    const float q = floorf((cl - r.nmin) * r.inv + 0.5f) * r.scale + r.nmin;
+    return (r.zero ? 0.0f : q) + r.back;
+}
+
+// Ranges of one block in mode 3 from its RAW packed parameters P (and the already quantised pis in qpi[]):
+// A_diagonal: offset form over the diagonals; A_corr: over the whole d x d matrices (the structural zeros
+// of the variable keep 0 inside the range); musX, gamma_e: plain; nu_e: offset form (smoe.py:497-530).
+template <int D, int C, int K>
+struct BlockRanges {
+    FqRange ad, ac, mu, nu, ga;
+    float lo[5], hi[5];     // 0 A_diag, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e (raw extremes, for the tie tests)
+    __device__ __forceinline__ void compute(const float* P, const bool (&keep)[K], const KernelConsts& kc) {
+        using Lt = Layout<D, C, K>;
+        constexpr float INF = __builtin_huge_valf();
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { lo[t] = INF; hi[t] = -INF; }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (!keep[k]) continue;
+            any = true;
+            const float* p = P + k * Lt::PK;
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                lo[2] = fminf(lo[2], p[Lt::O_MU + l]); hi[2] = fmaxf(hi[2], p[Lt::O_MU + l]);
+#pragma unroll
+                for (int m = 0; m <= l; ++m) {
+                    const float a = p[Lt::O_A + tri_index(l, m)];
+                    const int t = (l == m) ? 0 : 1;
+                    lo[t] = fminf(lo[t], a); hi[t] = fmaxf(hi[t], a);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) { lo[3] = fminf(lo[3], p[Lt::O_NU + c]); hi[3] = fmaxf(hi[3], p[Lt::O_NU + c]); }
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) { lo[4] = fminf(lo[4], p[Lt::O_GA + i]); hi[4] = fmaxf(hi[4], p[Lt::O_GA + i]); }
+        }
+        lo[1] = fminf(lo[1], 0.0f); hi[1] = fmaxf(hi[1], 0.0f);          // diagonal / upper entries of the A_corr variable
+        if (!any) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { lo[t] = 0.0f; hi[t] = 0.0f; }
+        }
+        ad = fq_vars(lo[0], hi[0], kc.q_levels[0], true);
+        ac = fq_vars(lo[1], hi[1], kc.q_levels[0], false);
+        mu = fq_vars(lo[2], hi[2], kc.q_levels[1], false);
+        nu = fq_vars(lo[3], hi[3], kc.q_levels[2], true);
+        ga = fq_vars(lo[4], hi[4], kc.q_levels[4], false);
+    }
+};
+
+// Replace the packed parameters P by the fake-quantised values the graph is built on.
+// FULL = false: only the pis (quantize_pis, the reference CLI default) -- a few instructions, kept as a
+// run-time branch in the default kernels; modes 2 / 3 live in their own instantiations (QUANT) so that their
+// register footprint does not reach the hot kernels.
+template <int D, int C, int K, bool FULL>
+__device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc) {
+    using Lt = Layout<D, C, K>;
+    if (kc.qpis) {
+        const FqRange r = fq_fixed(kc, 3);
+#pragma unroll
+        for (int k = 0; k < K; ++k) P[k * Lt::PK + Lt::O_PI] = fq_val(P[k * Lt::PK + Lt::O_PI], r);
+    }
+    if constexpr (!FULL) return;
+    if (kc.qmode == 2) {
+        const FqRange ra = fq_fixed(kc, 0), rm = fq_fixed(kc, 1), rn = fq_fixed(kc, 2), rg = fq_fixed(kc, 4);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float* p = P + k * Lt::PK;
+#pragma unroll
+            for (int l = 0; l < D; ++l) p[Lt::O_MU + l] = fq_val(p[Lt::O_MU + l], rm);
+#pragma unroll
+            for (int i = 0; i < Lt::TRI; ++i) p[Lt::O_A + i] = fq_val(p[Lt::O_A + i], ra);
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[Lt::O_NU + c] = fq_val(p[Lt::O_NU + c], rn);
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) p[Lt::O_GA + i] = fq_val(p[Lt::O_GA + i], rg);
+        }
+    } else if (kc.qmode == 3) {
+        bool keep[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) keep[k] = P[k * Lt::PK + Lt::O_PI] > 0.0f;     // pis_mask = qpis > 0
+        BlockRanges<D, C, K> br;
+        br.compute(P, keep, kc);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float* p = P + k * Lt::PK;
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                if (kc.q_musx) p[Lt::O_MU + l] = fq_val(p[Lt::O_MU + l], br.mu);
+#pragma unroll
+                for (int m = 0; m <= l; ++m)
+                    p[Lt::O_A + tri_index(l, m)] = fq_val(p[Lt::O_A + tri_index(l, m)], (l == m) ? br.ad : br.ac);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[Lt::O_NU + c] = fq_val(p[Lt::O_NU + c], br.nu);
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) p[Lt::O_GA + i] = fq_val(p[Lt::O_GA + i], br.ga);
+        }
+    }
+}
+
+// Backward of the mode-3 fake-quant ops on this lane's partial gradients acc[] (linear, so it commutes with
+// the cross-lane sum): inside the nudged range the gradient passes; what falls below / above goes to the
+// min / max input and from there (reduce_min / reduce_max) to the extreme elements, split over ties.
+// (Fixed ranges -- pis, mode 2 -- are plain per-element masks and are applied by the slot owners on the
+// reduced totals.)  Praw: the block's RAW packed parameters.
+template <int D, int C, int K>
+__device__ __forceinline__ void route_quant_partials(const float* Praw, const KernelConsts& kc, float* __restrict__ acc) {
+    using Lt = Layout<D, C, K>;
+    if (kc.qmode == 3) {
+        bool keep[K];
+        const FqRange rp = fq_fixed(kc, 3);
+#pragma unroll
+        for (int k = 0; k < K; ++k) keep[k] = fq_val(Praw[k * Lt::PK + Lt::O_PI], rp) > 0.0f;
+        BlockRanges<D, C, K> br;
+        br.compute(Praw, keep, kc);
+        // per tensor t: sums of the gradients that fall below / above, tie counts at the raw extremes
+        float GL[5], GA[5], nlo[5], nhi[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { GL[t] = GA[t] = 0.0f; nlo[t] = nhi[t] = 0.0f; }
+        auto tensor_of = [](int o) {      // packed offset -> 0 A_diag, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e
+            if (o < Lt::O_A) return 2;
+            if (o < Lt::O_NU) {
+                const int t = o - Lt::O_A;
+                int l = 0;
+                while ((l + 1) * (l + 2) / 2 <= t) ++l;
+                return (t - l * (l + 1) / 2 == l) ? 0 : 1;
+            }
+            return (o < Lt::O_GA) ? 3 : 4;
+        };
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int o = Lt::O_MU; o < Lt::PK; ++o) {
+                const int j = k * Lt::PK + o;
+                const int t = tensor_of(o);
+                if (t == 2 && !kc.q_musx) continue;
+                const FqRange& r = (t == 0) ? br.ad : ((t == 1) ? br.ac : ((t == 2) ? br.mu : ((t == 3) ? br.nu : br.ga)));
+                const float x = Praw[j], v = x - r.back;
+                const bool below = !r.zero && (v < r.nmin), above = !r.zero && (v > r.nmax);
+                GL[t] += below ? acc[j] : 0.0f;
+                GA[t] += above ? acc[j] : 0.0f;
+                nlo[t] += (keep[k] && x == br.lo[t]) ? 1.0f : 0.0f;
+                nhi[t] += (keep[k] && x == br.hi[t]) ? 1.0f : 0.0f;
+                acc[j] = (below || above) ? 0.0f : acc[j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            GL[t] = GL[t] / fmaxf(nlo[t], 1.0f);
+            GA[t] = GA[t] / fmaxf(nhi[t], 1.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int o = Lt::O_MU; o < Lt::PK; ++o) {
+                const int j = k * Lt::PK + o;
+                const int t = tensor_of(o);
+                if (t == 2 && !kc.q_musx) continue;
+                const float x = Praw[j];
+                acc[j] += (keep[k] && x == br.lo[t]) ? GL[t] : 0.0f;
+                acc[j] += (keep[k] && x == br.hi[t]) ? GA[t] : 0.0f;
+            }
+        }
+    }
+}
+
 // G == 64: the wavefront owns ONE block, so everything derived from its parameters is
 // wave-uniform and could live in SGPRs.  Measured on MI355X this is a LOSS (VALU forms with an
 // SGPR source issue at ~4.8 vs ~3.2 cycles and the readfirstlanes add ~100 instructions per
@@ -811,7 +1014,8 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // SSIM (ssim_opt, G == 64 and D == 2 only): loss_pixel = 1 - SSIM.  Per iteration: a forward-only sweep
 // leaves the quantised reconstruction of the block in LDS, the wavefront turns it into dL/dq
 // (ssim_block), and the usual fused sweep runs with that gradient instead of the margin loss.
-template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false>
+// QUANT: quantization_mode 2 / 3 (all variables fake-quantised in the graph).
+template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false>
 __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -864,11 +1068,12 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     // ---- owner set-up: this lane owns packed slots sub, sub+G, ... of its block --------
     // per-slot learning rate (0 = not trained) and l1 regulariser constant stay in registers;
     // the parameter and its Adam slots live in LDS between iterations.
-    float lr[T::SPL], reg[T::SPL];
+    float lr[T::SPL], reg[T::SPL], qlo[T::SPL], qhi[T::SPL];
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
         const int j = sub + s * G;
         lr[s] = reg[s] = 0.0f;
+        qlo[s] = -__builtin_huge_valf(); qhi[s] = __builtin_huge_valf();
         if (j < Lt::NPAR) {
             int tensor, kern; long off;
             decode_slot<D, C, K>(j, b, tensor, off, kern);
@@ -883,6 +1088,9 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             if (tensor == 4 && a.kc.only_y_gamma && (off % C) != 0) r = 0.0f;   // masked slopes get zero gradient
             lr[s] = r;
             reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? a.reg_u : 0.0f);   // smoe.py:1027,1044
+            // fixed-range fake quant of this variable: the gradient passes inside the nudged range only
+            const int qg = (tensor == 0) ? 3 : ((tensor == 1) ? 1 : ((tensor == 4) ? 4 : ((tensor == 5) ? 2 : 0)));
+            if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) { qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; }
         } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
             const int k = j - Lt::S_CNT;
             s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
@@ -893,6 +1101,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     const float loss0 = (a.loss0 != nullptr) ? a.loss0[b] : 0.0f;
     const bool has_loss0 = a.loss0 != nullptr;
     const bool has_reg = (a.reg_pi != 0.0f) || (a.reg_u != 0.0f);
+    const bool has_quant = (a.kc.qmode != 0) || (a.kc.qpis != 0);
     float last_loss = 0.0f, last_sse = 0.0f;
     __syncthreads();
 
@@ -910,6 +1119,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         {
             BlockRegs<D, C, K> R;
             R.load(s_par);
+            if (has_quant) quantize_packed<D, C, K, QUANT>(R.P, kc);     // the graph sees the fake-quantised variables
             R.derive(kc);
             frozen = R.frozen();
             if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
@@ -966,7 +1176,13 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
             R2.load(s_par);
+            if (has_quant) quantize_packed<D, C, K, QUANT>(R2.P, kc);
             finish_partials<D, C, K>(R2, kc, acc);
+        }
+        if constexpr (QUANT) if (kc.qmode == 3) {            // back through fake_quant_with_min_max_vars
+            BlockRegs<D, C, K> R3;
+            R3.load(s_par);
+            route_quant_partials<D, C, K>(R3.P, kc, acc);
         }
 
         float total[T::SPL];
@@ -986,9 +1202,12 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             float gsum = total[s];
             if (has_reg && reg[s] != 0.0f) {
                 const int k = jc / Lt::PK;
-                const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (s_par[k * Lt::PK + Lt::O_PI] > 0.0f);
+                float piv = s_par[k * Lt::PK + Lt::O_PI];
+                if (kc.qpis) piv = fq_val(piv, fq_fixed(kc, 3));
+                const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (piv > 0.0f);
                 gsum += act ? reg[s] : 0.0f;
             }
+            gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;     // fixed-range fake quant: straight-through inside
             if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
             const float alpha = lr[s] * bias;
             const float m2 = mv + (gsum - mv) * (1.0f - beta1);
@@ -1052,7 +1271,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 // ---------------------------------------------------------------------------
 // forward (evaluation) kernel
 // ---------------------------------------------------------------------------
-template <int D, int C, int K, int G, int WAVES, bool SSIM = false>
+template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false>
 __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -1113,6 +1332,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
 
     BlockRegs<D, C, K> R;
     R.load(s_par);
+    if (a.kc.qmode != 0 || a.kc.qpis != 0) quantize_packed<D, C, K, QUANT>(R.P, a.kc);
     R.derive(a.kc);
 
     float acc[Lt::NSLOT];
@@ -1258,6 +1478,60 @@ __global__ void readmit_kernel(ReadmitArgs a) {
     if (near && a.p.pis[bk] > 0.0f) atomicOr(&a.active[b], 1u << k);
 }
 
+// update_kernel_list when the graph is built on fake-quantised variables: the probe test (smoe.py:806) sees
+// q(A), q(musX) and pis_mask = qpis > 0.  One thread per block (mode-3 ranges need all its kernels).
+template <int D, int C, int K>
+__global__ void readmit_quant_kernel(ReadmitArgs a, KernelConsts kc) {
+    using Lt = Layout<D, C, K>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    float P[Lt::NPAR];
+#pragma unroll
+    for (int j = 0; j < Lt::NPAR; ++j) {
+        int tensor, kern; long off;
+        decode_slot<D, C, K>(j, b, tensor, off, kern);
+        P[j] = pick(a.p, tensor)[off];
+    }
+    quantize_packed<D, C, K, true>(P, kc);
+    int nprobe = 1;
+#pragma unroll
+    for (int l = 0; l < D; ++l) nprobe *= 3;
+    uint32_t add = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float* p = P + k * Lt::PK;
+        bool near = false;
+        for (int q = 0; q < nprobe; ++q) {
+            float r[D];
+            int rem = q;
+#pragma unroll
+            for (int l = D - 1; l >= 0; --l) {
+                const int sel = rem % 3;
+                rem /= 3;
+                r[l] = a.probes[l * 3 + sel] - p[Lt::O_MU + l];
+            }
+            float maha = 0.0f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float zz = 0.0f;
+#pragma unroll
+                for (int l = m; l < D; ++l) zz = fmaf(r[l], p[Lt::O_A + tri_index(l, m)], zz);
+                maha = fmaf(zz, zz, maha);
+            }
+            near = near || (maha < 800.0f);
+        }
+        if (near && p[Lt::O_PI] > 0.0f) add |= 1u << k;
+    }
+    a.active[b] |= add;
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_readmit_quant(const ReadmitArgs& a, const KernelConsts& kc, hipStream_t st) {
+    const int threads = 64;
+    hipLaunchKernelGGL((readmit_quant_kernel<D, C, K>), dim3((a.B + threads - 1) / threads), dim3(threads), 0, st, a, kc);
+    return hipGetLastError();
+}
+
 // checkpoint_best_op, smoe.py:861-896 (trigger 1574-1576), per block
 __global__ void best_kernel(BestArgs a) {
     const int b = blockIdx.x;
@@ -1352,6 +1626,34 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// quantization_mode 2 / 3 launches
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 0, false, true>;
+    int hl = 0;
+    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, true>; hl = 1; }
+    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
+    auto kern = forward_kernel<D, C, K, G, WAVES, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
 // ssim_opt launches: instantiated for 2-d blocks on the one-block-per-wavefront tiling only
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
@@ -1411,7 +1713,8 @@ int fit_occupancy(int N, bool has_lw) {
 
 #define SMOE_VARIANT(D, C, K, G, W) \
     { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
-      &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W> }
+      &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W>, \
+      &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W> }
 
 static const Variant g_variants[] = {
     SMOE_VARIANT(2, 1, 4, 16, 4), SMOE_VARIANT(2, 1, 4, 64, 2),

@@ -49,6 +49,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Fixed-range fake quant of the variables inside the graph (quantize_pis; quantization_mode 2; smoe.py:474-496):
+// group g: 0 A, 1 musX, 2 nu_e, 3 pis, 4 gamma_e.  (Mode 3 needs image-wide ranges and is not built for this mode.)
+__device__ __forceinline__ bool fq_on(const KernelConsts& kc, int g) { return (g == 3) ? (kc.qpis != 0) : (kc.qmode == 2); }
+__device__ __forceinline__ float fqv(float x, const KernelConsts& kc, int g) {
+    if (!fq_on(kc, g)) return x;
+    const float cl = fminf(fmaxf(x, kc.q_nmin[g]), kc.q_nmax[g]);
+    return floorf((cl - kc.q_nmin[g]) * kc.q_inv[g] + 0.5f) * kc.q_scale[g] + kc.q_nmin[g];
+}
+__device__ __forceinline__ bool fq_pass(float x, const KernelConsts& kc, int g) {
+    return !fq_on(kc, g) || (x >= kc.q_nmin[g] && x <= kc.q_nmax[g]);
+}
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 }  // namespace
@@ -83,7 +95,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     for (int base = 0; base < K; base += SH_THREADS) {
         const int k = base + tid;
         bool act = false;
-        if (k < K) act = ((bits[k >> 5] >> (k & 31)) & 1u) && (a.p.pis[k] > 0.0f);
+        if (k < K) act = ((bits[k >> 5] >> (k & 31)) & 1u) && (fqv(a.p.pis[k], a.kc, 3) > 0.0f);
         const unsigned long long m = __ballot(act);
         if (lane == 0) s_cnt[1 + wave] = __popcll(m);
         __syncthreads();
@@ -140,7 +152,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int l = 0; l < D; ++l)
 #pragma unroll
                 for (int m = 0; m <= l; ++m) {
-                    A[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m];
+                    A[l][m] = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
                     if (l == m) det *= A[l][m];
                     r[L::O_AS + tri(l, m)] = SQ * A[l][m];
                 }
@@ -148,16 +160,16 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int m = 0; m < D; ++m) {
                 float cz = 0.0f;
 #pragma unroll
-                for (int l = m; l < D; ++l) cz = fmaf(a.p.musX[(size_t)k * D + l], SQ * A[l][m], cz);
+                for (int l = m; l < D; ++l) cz = fmaf(fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * A[l][m], cz);
                 r[L::O_CZ + m] = cz;
             }
             const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
-            r[L::O_COEF] = nq * a.p.pis[k];
+            r[L::O_COEF] = nq * fqv(a.p.pis[k], a.kc, 3);
 #pragma unroll
-            for (int c = 0; c < C; ++c) r[L::O_NU + c] = a.p.nu_e[(size_t)k * C + c];
+            for (int c = 0; c < C; ++c) r[L::O_NU + c] = fqv(a.p.nu_e[(size_t)k * C + c], a.kc, 2);
 #pragma unroll
             for (int i = 0; i < D * C; ++i)
-                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? a.p.gamma_e[(size_t)k * D * C + i] : 0.0f;
+                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? fqv(a.p.gamma_e[(size_t)k * D * C + i], a.kc, 4) : 0.0f;
         }
         __syncthreads();
     };
@@ -266,14 +278,14 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                     float zz = 0.0f;
 #pragma unroll
                     for (int l = m; l < D; ++l) {
-                        const float Alm = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m];
+                        const float Alm = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
                         if (l == m) det *= Alm;
-                        zz = fmaf(xh[l] - a.p.musX[(size_t)k * D + l], SQ * Alm, zz);
+                        zz = fmaf(xh[l] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * Alm, zz);
                     }
                     maha = fmaf(zz, zz, maha);
                 }
                 const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
-                Sh += nq * a.p.pis[k] * fexp2(-maha);
+                Sh += nq * fqv(a.p.pis[k], a.kc, 3) * fexp2(-maha);
             }
             const float invh = frcp(fmaxf(Sh, 10e-12f));
             for (int i = 0; i < Kact; ++i) {
@@ -284,14 +296,14 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                     float zz = 0.0f;
 #pragma unroll
                     for (int l = m; l < D; ++l) {
-                        const float Alm = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m];
+                        const float Alm = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
                         if (l == m) det *= Alm;
-                        zz = fmaf(xh[l] - a.p.musX[(size_t)k * D + l], SQ * Alm, zz);
+                        zz = fmaf(xh[l] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * Alm, zz);
                     }
                     maha = fmaf(zz, zz, maha);
                 }
                 const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
-                if (nq * a.p.pis[k] * fexp2(-maha) * invh > a.kc.tau) s_flag[i] = 1;
+                if (nq * fqv(a.p.pis[k], a.kc, 3) * fexp2(-maha) * invh > a.kc.tau) s_flag[i] = 1;
             }
         }
         __syncthreads();
@@ -392,8 +404,8 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {                    // smoe.py:1027,1044 over the batch's active kernels
             for (int i = 0; i < Kact; ++i) {
                 const int k = s_list[i];
-                lossv += a.reg_pi * a.p.pis[k];
-                for (int l = 0; l < D; ++l) lossv += a.reg_u * a.p.A_diagonal[((size_t)k * D + l) * D + l];
+                lossv += a.reg_pi * fqv(a.p.pis[k], a.kc, 3);
+                for (int l = 0; l < D; ++l) lossv += a.reg_u * fqv(a.p.A_diagonal[((size_t)k * D + l) * D + l], a.kc, 0);
             }
         }
         if (a.loss != nullptr) a.loss[b] = lossv;
@@ -437,14 +449,19 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
     for (int j = 0; j < L::PK; ++j) { r[j] = (float)rk[j]; rk[j] = 0.0; }
     const float nact = a.nact ? (float)a.nact[k] : 0.0f;
     if (a.nact) a.nact[k] = 0.0;
-    const float pi = a.p.pis[k];
-    float A[D][D], mu[D];
+    // the gradients are those of the fake-quantised variables, passed straight through inside the nudged range
+    const float pi_raw = a.p.pis[k];
+    const float pi = fqv(pi_raw, a.kc, 3);
+    float A[D][D], Araw[D][D], mu[D], mu_raw[D];
 #pragma unroll
     for (int l = 0; l < D; ++l) {
-        mu[l] = a.p.musX[(size_t)k * D + l];
+        mu_raw[l] = a.p.musX[(size_t)k * D + l];
+        mu[l] = fqv(mu_raw[l], a.kc, 1);
 #pragma unroll
-        for (int m = 0; m < D; ++m)
-            A[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+        for (int m = 0; m < D; ++m) {
+            Araw[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+            A[l][m] = (l >= m) ? fqv(Araw[l][m], a.kc, 0) : 0.0f;
+        }
     }
     const float su = r[L::R_SU];
     float suz[D];
@@ -452,7 +469,8 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
     for (int m = 0; m < D; ++m) suz[m] = r[L::R_SUZ + m] * INV_SQ;
     // pis (optimizer2)
     if (a.train_pis) {
-        const float g = (pi > 0.0f ? su / pi : 0.0f) + nact * a.reg_pi;
+        float g = (pi > 0.0f ? su / pi : 0.0f) + nact * a.reg_pi;
+        g = fq_pass(pi_raw, a.kc, 3) ? g : 0.0f;
         adam_apply(&a.p.pis[k], &a.m.pis[k], &a.v.pis[k], g, a.lr_pis, a);
     }
     // musX (optimizer1)
@@ -462,6 +480,7 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
             float g = 0.0f;
 #pragma unroll
             for (int m = 0; m <= l; ++m) g = fmaf(A[l][m], suz[m], g);
+            g = fq_pass(mu_raw[l], a.kc, 1) ? g : 0.0f;
             const size_t o = (size_t)k * D + l;
             adam_apply(&a.p.musX[o], &a.m.musX[o], &a.v.musX[o], g, a.lr_expert, a);
         }
@@ -476,6 +495,9 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
             if (l == m) {
                 if (a.use_det) g += su / A[l][l];
                 g += nact * a.reg_u;
+            }
+            g = fq_pass(Araw[l][m], a.kc, 0) ? g : 0.0f;
+            if (l == m) {
                 adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], g, a.lr_steer, a);
             } else {
                 adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], g, a.lr_steer, a);
@@ -485,14 +507,14 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const size_t o = (size_t)k * C + c;
-        adam_apply(&a.p.nu_e[o], &a.m.nu_e[o], &a.v.nu_e[o], r[L::R_SWG + c], a.lr_expert, a);
+        adam_apply(&a.p.nu_e[o], &a.m.nu_e[o], &a.v.nu_e[o], fq_pass(a.p.nu_e[o], a.kc, 2) ? r[L::R_SWG + c] : 0.0f, a.lr_expert, a);
     }
     if (a.train_gammas) {
 #pragma unroll
         for (int i = 0; i < D * C; ++i) {
             const size_t o = (size_t)k * D * C + i;
             if (a.only_y_gamma && (i % C) != 0) continue;
-            adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], r[L::R_SWGX + i], a.lr_expert, a);
+            adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], fq_pass(a.p.gamma_e[o], a.kc, 4) ? r[L::R_SWGX + i] : 0.0f, a.lr_expert, a);
         }
     }
 }
@@ -504,13 +526,14 @@ __global__ void shared_readmit_kernel(SharedReadmitArgs a) {
     if (t >= (long)a.NB * a.K) return;
     const int b = (int)(t / a.K);
     const int k = (int)(t - (long)b * a.K);
-    if (!(a.p.pis[k] > 0.0f)) return;
+    if (!(fqv(a.p.pis[k], a.kc, 3) > 0.0f)) return;
     float A[D][D];
 #pragma unroll
     for (int l = 0; l < D; ++l)
 #pragma unroll
         for (int m = 0; m < D; ++m)
-            A[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+            A[l][m] = (l == m) ? fqv(a.p.A_diagonal[((size_t)k * D + l) * D + m], a.kc, 0)
+                               : ((l > m) ? fqv(a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0) : 0.0f);
     int nprobe = 1;
 #pragma unroll
     for (int l = 0; l < D; ++l) nprobe *= 3;
@@ -522,7 +545,7 @@ __global__ void shared_readmit_kernel(SharedReadmitArgs a) {
         for (int l = D - 1; l >= 0; --l) {
             const int sel = rem % 3;
             rem /= 3;
-            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - a.p.musX[(size_t)k * D + l];
+            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1);
         }
         float maha = 0.0f;
 #pragma unroll

@@ -42,6 +42,12 @@ class EngineConfig:
     start_pis: int = 0
     only_y_gamma: bool = False
     ssim_opt: bool = False
+    # fake-quantised variables in the graph (smoe.py:474-538); tuples ordered A, musX, nu_e, pis, gamma_e
+    quantization_mode: int = 0
+    quantize_pis: bool = False
+    bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
+    lower_bounds: Sequence[float] = (-2500, -.3, -5, 0, -32)
+    upper_bounds: Sequence[float] = (2500, 1.3, 5, 2, 32)
 
     @property
     def dim(self) -> int:
@@ -106,6 +112,10 @@ class BlockEngine:
         c.start_pis = cfg.start_pis or cfg.kernels
         c.only_y_gamma = int(cfg.only_y_gamma)
         c.ssim_opt = int(cfg.ssim_opt)
+        c.quantization_mode, c.quantize_pis = int(cfg.quantization_mode), int(cfg.quantize_pis)
+        for i in range(5):
+            c.bit_depths[i] = int(cfg.bit_depths[i])
+            c.lower_bounds[i], c.upper_bounds[i] = float(cfg.lower_bounds[i]), float(cfg.upper_bounds[i])
         self._c = c
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_create(C.byref(self._h), C.byref(c)))
@@ -261,6 +271,11 @@ class SharedConfig:
     start_pis: int = 0
     only_y_gamma: bool = False
     overlap: int = 0
+    quantization_mode: int = 0
+    quantize_pis: bool = False
+    bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
+    lower_bounds: Sequence[float] = (-2500, -.3, -5, 0, -32)
+    upper_bounds: Sequence[float] = (2500, 1.3, 5, 2, 32)
 
     @property
     def dim(self) -> int:
@@ -291,6 +306,10 @@ class SharedEngine:
         c.start_pis = cfg.start_pis or cfg.kernels
         c.only_y_gamma = int(cfg.only_y_gamma)
         c.overlap = int(cfg.overlap)
+        c.quantization_mode, c.quantize_pis = int(cfg.quantization_mode), int(cfg.quantize_pis)
+        for i in range(5):
+            c.bit_depths[i] = int(cfg.bit_depths[i])
+            c.lower_bounds[i], c.upper_bounds[i] = float(cfg.lower_bounds[i]), float(cfg.upper_bounds[i])
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_shared_create(C.byref(self._h), C.byref(c)))
         self.num_batches = int(self.lib.smoe_shared_num_batches(self._h))

@@ -45,6 +45,20 @@ def _default_engine_factory(cfg: EngineConfig, device):
     return BlockEngine(cfg, device)
 
 
+def _fake_quant_fixed(x: torch.Tensor, lb: float, ub: float, bits: int) -> torch.Tensor:
+    """tf.quantization.fake_quant_with_min_max_args in fp32 (TF Nudge(): the zero point is rounded so that 0 stays
+    representable), for host-side bookkeeping only -- the fit itself quantises inside the kernels."""
+    f = torch.float32
+    levels = torch.tensor(float(2 ** bits - 1), dtype=f)
+    mn, mx = torch.tensor(float(lb), dtype=f), torch.tensor(float(ub), dtype=f)
+    scale = (mx - mn) / levels
+    zp = -mn / scale
+    nzp = torch.clamp(torch.sign(zp) * torch.floor(zp.abs() + 0.5), 0.0, float(levels))
+    nmin, nmax = (0.0 - nzp) * scale, (levels - nzp) * scale
+    cl = torch.minimum(torch.maximum(x.to(f), nmin.to(x.device)), nmax.to(x.device))
+    return torch.floor((cl - nmin.to(x.device)) * (1.0 / scale).to(x.device) + 0.5) * scale.to(x.device) + nmin.to(x.device)
+
+
 class Smoe:
     def __init__(self, image, kernels_per_dim=None, train_pis=True, init_params=None, start_batches=1,
                  batch_size=None, train_gammas=True, train_musx=True, use_diff_center=False, radial_as=False,
@@ -63,9 +77,13 @@ class Smoe:
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"Smoe({name}=True) is outside the per-block hot path (SURVEY section 8)")
-        if quantization_mode not in (0, 1):
-            raise NotImplementedError("quantisation-aware fitting (fake-quant modes 2/3) is outside the hot path; "
-                                      "mode 1 (quantise at validation, quantizer.py) is supported")
+        if quantization_mode not in (0, 1, 2, 3):
+            raise ValueError("quantization_mode must be 0, 1, 2 or 3")                # smoe_test.py:298-301
+        if quantization_mode >= 2 and use_diff_center:
+            raise NotImplementedError("fake-quantised centre OFFSETS (use_diff_center with quantization_mode 2/3) "
+                                      "are not built: the engine works on absolute centres")
+        if quantization_mode >= 2 and ssim_opt:
+            raise NotImplementedError("ssim_opt together with quantization_mode 2/3 is not instantiated")
         if add_kernel_slots:
             raise NotImplementedError("progressive kernel adding changes K over time; not part of the hot path")
         if overlap_of_batches:
@@ -87,10 +105,11 @@ class Smoe:
         self.radial_as = radial_as
         self.use_determinant = use_determinant
         self.quantization_mode = quantization_mode
-        self.quantize_pis = quantize_pis
-        self.bit_depths = bit_depths
-        self.lower_bounds = lower_bounds
-        self.upper_bounds = upper_bounds
+        self.quantize_pis = bool(quantize_pis) or quantization_mode >= 2               # smoe_test.py:36-37, smoe.py:474
+        # bit depths / bounds in the order A, musX, nu_e, pis, gamma_e; None -> the CLI defaults (smoe_test.py:302-309)
+        self.bit_depths = [20, 18, 6, 10, 10] if bit_depths is None else list(bit_depths)
+        self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
+        self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
         self.train_pis, self.train_gammas, self.train_musx = train_pis, train_gammas, train_musx
         self.train_inverse_cov = train_inverse_cov
         self.train_trafo = train_trafo
@@ -226,7 +245,10 @@ class Smoe:
             beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999,
             adam_eps=o1._epsilon if o1 else 1e-8,
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
-            start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma), ssim_opt=bool(self.ssim_opt))
+            start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma), ssim_opt=bool(self.ssim_opt),
+            quantization_mode=int(self.quantization_mode), quantize_pis=bool(self.quantize_pis),
+            bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
+            upper_bounds=tuple(self.upper_bounds))
         key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
         key = repr(key)
         if key != self._engine_key:
@@ -257,7 +279,10 @@ class Smoe:
     # -- passes ----------------------------------------------------------------------------
     def _global(self, loss, sse):
         s = self._engine.reduce_scalars(loss, sse, None)
-        npi = (self._params["pis"] > 0).sum().to(torch.float64)
+        pis = self._params["pis"]
+        if self.quantize_pis:                                        # num_pi_op counts pis_mask = qpis > 0 (smoe.py:480,1012)
+            pis = _fake_quant_fixed(pis, self.lower_bounds[3], self.upper_bounds[3], self.bit_depths[3])
+        npi = (pis > 0).sum().to(torch.float64)
         s[2] = npi
         sdist.allreduce_sum_(s)
         s = s.cpu().numpy()
@@ -342,9 +367,10 @@ class Smoe:
         self._make_engine(pis_l1, u_l1)
         eng = self._engine
 
-        if self.quantization_mode >= 1:                                   # smoe.py:1498-1505
+        if self.quantization_mode >= 1:                                   # smoe.py:1498-1499
             from .quantizer import quantize_params, rescaler
             self.qparams = quantize_params(self, self.get_params())
+        if self.quantization_mode == 1:                                   # smoe.py:1500-1505
             self.rparams = rescaler(self, self.qparams)
             self.best_qloss, self.best_qmse, _, _ = self.run_batched(
                 pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True, with_quantized_params=True)
@@ -384,9 +410,10 @@ class Smoe:
                     if not validate:
                         loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
                 if validate:                                                  # smoe.py:1538-1594
-                    if self.quantization_mode >= 1:                           # smoe.py:1539-1545
+                    if self.quantization_mode >= 1:                           # smoe.py:1539-1540
                         from .quantizer import quantize_params, rescaler
                         self.qparams = quantize_params(self, self.get_params())
+                    if self.quantization_mode == 1:                           # smoe.py:1541-1545
                         self.rparams = rescaler(self, self.qparams)
                         qloss_val, qmse_val, _, _ = self.run_batched(
                             pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True,
@@ -549,10 +576,14 @@ class SharedSmoe:
     def __init__(self, image, kernels_per_dim=None, train_pis=True, init_params=None, start_batches=1,
                  batch_size=None, train_gammas=True, train_musx=True, use_determinant=False, normalize_pis=True,
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
-                 engine_factory=None, **unsupported):
+                 engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
+                 upper_bounds=None, **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
+        if quantization_mode not in (0, 2):
+            raise NotImplementedError("SharedSmoe: quantization_mode 0 and 2 (fixed ranges) are built; mode 1 (quantise at "
+                                      "validation) and mode 3 (image-wide min/max ranges) are not")
         assert kernels_per_dim is not None or init_params is not None, \
             "You need to specify the kernel grid size or give initial parameters."
         image = np.asarray(image, dtype=np.float32)
@@ -563,8 +594,11 @@ class SharedSmoe:
         self.use_yuv = bool(use_yuv) and image.shape[-1] == 3
         self.use_determinant = use_determinant
         self.train_pis, self.train_gammas, self.train_musx = train_pis, train_gammas, train_musx
-        self.quantization_mode, self.quantize_pis = 0, False
-        self.bit_depths = self.lower_bounds = self.upper_bounds = None
+        self.quantization_mode = int(quantization_mode)
+        self.quantize_pis = bool(quantize_pis) or quantization_mode >= 2           # smoe.py:474, smoe_test.py:36-37
+        self.bit_depths = [20, 18, 6, 10, 10] if bit_depths is None else list(bit_depths)
+        self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
+        self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
         self.only_y_gamma = self.ssim_opt = self.use_diff_center = self.radial_as = False
         self.overlap = int(overlap_of_batches)                            # smoe.py:244
         if batch_size is None or batch_size[0] is None:
@@ -625,7 +659,9 @@ class SharedSmoe:
             lr_expert=o1._lr if o1 else 0.0, lr_pis=o2._lr if o2 else 0.0, lr_steer=o3._lr if o3 else 0.0,
             beta1=o1._beta1 if o1 else 0.9, beta2=o1._beta2 if o1 else 0.999, adam_eps=o1._epsilon if o1 else 1e-8,
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
-            start_pis=self.kernels, overlap=self.overlap)
+            start_pis=self.kernels, overlap=self.overlap, quantization_mode=self.quantization_mode,
+            quantize_pis=self.quantize_pis, bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
+            upper_bounds=tuple(self.upper_bounds))
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:
@@ -654,7 +690,10 @@ class SharedSmoe:
         s = s.cpu().numpy()
         loss_val = float(s[0]) * self.Nb / self.num_pixel                              # smoe.py:1758
         mse_val = float(s[1]) / (self.num_pixel * self.image.shape[-1]) * (2 ** self.precision) ** 2
-        return loss_val, mse_val, int((self._params["pis"] > 0).sum().item())
+        pis = self._params["pis"]
+        if self.quantize_pis:                                        # pis_mask = qpis > 0 (smoe.py:480,1012)
+            pis = _fake_quant_fixed(pis, self.lower_bounds[3], self.upper_bounds[3], self.bit_depths[3])
+        return loss_val, mse_val, int((pis > 0).sum().item())
 
     def run_batched(self, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, train=True, update_reconstruction=False, **kw):
         for name, val in kw.items():

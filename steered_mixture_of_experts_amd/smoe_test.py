@@ -8,7 +8,7 @@ three Adam optimizers with ``base_lr``, ``base_lr/lr_div``, ``base_lr*lr_mult``
 ``--mode blocks`` (default): every ``-bz`` block is an independent model with ``-k`` kernels per axis
 (the per-block hot path).  ``--mode shared``: the reference's whole-image fit -- ``-k`` is the GLOBAL
 kernel grid and ``-bz`` the pixel batch of a pass.  Flags of features that are not built (kernel
-adding, support vectors, motion models, fake-quant training, sampling; batch overlap outside
+adding, support vectors, motion models, sampling; batch overlap outside
 ``--mode shared``, SSIM outside ``--mode blocks``) are
 accepted for command-line compatibility but must keep their inactive values.
 """
@@ -101,8 +101,8 @@ def main(args):
                                       "(SURVEY section 8) and is not built")
     if args.overlap_of_batches and args.mode != 'shared':
         raise NotImplementedError("--overlap_of_batches needs --mode shared (independent blocks have no neighbours)")
-    if args.quantization_mode >= 2:
-        raise NotImplementedError("fake-quantisation training (modes 2/3) is not built; mode 1 is")
+    if args.quantization_mode >= 2:                                                   # smoe_test.py:36-37
+        args.quantize_pis = True
     orig, precision, _ = read_image(args.image_path, args.use_yuv)                    # smoe_test.py:39
     use_yuv = args.use_yuv and orig.shape[-1] == 3                                    # smoe_test.py:41-44
     only_y_gamma = args.only_y_gamma and use_yuv
@@ -121,13 +121,15 @@ def main(args):
                   normalize_pis=args.normalize_pis, use_yuv=use_yuv, precision=precision)
     if args.mode == 'blocks':
         smoe = Smoe(orig, kpd, use_diff_center=args.use_diff_center, quantization_mode=args.quantization_mode,
-                    bit_depths=args.bit_depths, quantize_pis=args.quantize_pis and args.quantization_mode >= 1,
+                    bit_depths=args.bit_depths, quantize_pis=args.quantize_pis,
                     lower_bounds=args.lower_bounds, upper_bounds=args.upper_bounds, only_y_gamma=only_y_gamma,
                     loss_mask=loss_mask, ssim_opt=args.ssim_opt, **common)
     else:
-        if args.use_diff_center or only_y_gamma or args.quantization_mode or loss_mask is not None or args.ssim_opt:
-            raise NotImplementedError("--mode shared supports the plain model only")
-        smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, **common)
+        if args.use_diff_center or only_y_gamma or loss_mask is not None or args.ssim_opt:
+            raise NotImplementedError("--mode shared: use_diff_center / only_y_gamma / loss masks / SSIM are not built")
+        smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, quantization_mode=args.quantization_mode,
+                          quantize_pis=args.quantize_pis, bit_depths=args.bit_depths, lower_bounds=args.lower_bounds,
+                          upper_bounds=args.upper_bounds, **common)
     optimizer1 = Adam(args.base_lr)                                                   # smoe_test.py:84-86
     optimizer2 = Adam(args.base_lr / args.lr_div)
     optimizer3 = Adam(args.base_lr * args.lr_mult)

@@ -39,7 +39,11 @@ class OracleEngine:
             lr_expert=cfg.lr_expert, lr_pis=cfg.lr_pis, lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2,
             adam_eps=cfg.adam_eps, grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1,
             start_pis=cfg.start_pis or cfg.kernels, only_y_gamma=getattr(cfg, 'only_y_gamma', False),
-            ssim_opt=getattr(cfg, 'ssim_opt', False))
+            ssim_opt=getattr(cfg, 'ssim_opt', False), quantization_mode=getattr(cfg, 'quantization_mode', 0),
+            quantize_pis=getattr(cfg, 'quantize_pis', False), bit_depths=tuple(getattr(cfg, 'bit_depths', (20, 18, 6, 10, 10))),
+            lower_bounds=tuple(getattr(cfg, 'lower_bounds', (-2500, -.3, -5, 0, -32))),
+            upper_bounds=tuple(getattr(cfg, 'upper_bounds', (2500, 1.3, 5, 2, 32))))
+        self.numpy_only = self.ocfg.ssim_opt or self.ocfg.quantization_mode >= 2     # what the plain-C restatement lacks
         self.coords = np.ascontiguousarray(o.block_coords(cfg.block_shape).T)
 
     def close(self):
@@ -57,7 +61,7 @@ class OracleEngine:
         B = target.shape[0]
         act = active.numpy().view(np.uint32)
         p = self._np(params)
-        if want_argmax or want_gate or self.ocfg.ssim_opt:
+        if want_argmax or want_gate or self.numpy_only:
             # the C oracle has no argmax / gate outputs and no SSIM loss: use the numpy one for those
             K = self.cfg.kernels
             mask = ((act[:, None] >> np.arange(K, dtype=np.uint32)[None, :]) & 1).astype(bool)
@@ -80,7 +84,7 @@ class OracleEngine:
             sse_out=None):
         act = active.numpy().view(np.uint32)
         state.beta_pow[:] = [state.c.beta1_power, state.c.beta2_power]      # restore() writes the c fields
-        if self.ocfg.ssim_opt:
+        if self.numpy_only:
             return self._fit_numpy(target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out)
         r = co.fit(self.ocfg, self.coords, target.numpy(), self._np(params), self._np(state.m), self._np(state.v), act,
                    n_iters, state.beta_pow, None if loss_w is None else loss_w.numpy(),
@@ -166,7 +170,11 @@ class OracleSharedEngine:
             margin=cfg.margin, use_determinant=cfg.use_determinant, use_yuv=cfg.use_yuv, train_pis=cfg.train_pis,
             train_gammas=cfg.train_gammas, train_musx=cfg.train_musx, lr_expert=cfg.lr_expert, lr_pis=cfg.lr_pis,
             lr_steer=cfg.lr_steer, beta1=cfg.beta1, beta2=cfg.beta2, adam_eps=cfg.adam_eps,
-            grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1, start_pis=cfg.start_pis or cfg.kernels)
+            grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1, start_pis=cfg.start_pis or cfg.kernels,
+            quantization_mode=getattr(cfg, 'quantization_mode', 0), quantize_pis=getattr(cfg, 'quantize_pis', False),
+            bit_depths=tuple(getattr(cfg, 'bit_depths', (20, 18, 6, 10, 10))),
+            lower_bounds=tuple(getattr(cfg, 'lower_bounds', (-2500, -.3, -5, 0, -32))),
+            upper_bounds=tuple(getattr(cfg, 'upper_bounds', (2500, 1.3, 5, 2, 32))))
         self.coords = o.global_batch_coords(cfg.image_shape, cfg.batch_shape)
         ov = int(getattr(cfg, "overlap", 0))
         self.halo = o.global_halo_coords(cfg.image_shape, cfg.batch_shape, ov) if ov > 0 else None

@@ -108,8 +108,9 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
-    for kw in ({"quantization_mode": 2}, {"overlap_of_batches": 2}, {"add_kernel_slots": 4},
-               {"train_svs": True}, {"radial_as": True}, {"train_inverse_cov": True}, {"quantization_mode": 3}):
+    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True},
+               {"train_inverse_cov": True}, {"quantization_mode": 3, "use_diff_center": True},
+               {"quantization_mode": 2, "ssim_opt": True}):
         with pytest.raises(NotImplementedError):
             Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
     with pytest.raises(AssertionError):
@@ -323,3 +324,65 @@ def test_ssim_opt_fits_one_minus_ssim():
                          "engine_factory": OracleEngine, **kw})
     with pytest.raises(ValueError):
         Smoe(img, kernels_per_dim=[2, 2], batch_size=[4, 16], ssim_opt=True, engine_factory=OracleEngine)
+
+
+@pytest.mark.parametrize("mode,qpis", [(0, True), (2, False), (3, False)])
+def test_fake_quantised_fit_through_the_facade(mode, qpis):
+    """quantize_pis / quantization_mode 2, 3 (smoe.py:474-538): the facade trains on the fake-quantised graph
+    (oracle.fit with the same configuration), counts kernels with qpis > 0 and keeps writing qparams at the
+    validation points (smoe.py:1498-1499,1539-1540)."""
+    img = _image(32, 32, seed=3)
+    kw = dict(quantization_mode=mode, quantize_pis=qpis, bit_depths=[14, 12, 8, 10, 10],
+              lower_bounds=[-60, -.3, -1, 0, -4], upper_bounds=[60, 1.3, 2, 2, 4])
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
+    assert s.quantize_pis                                     # implied by modes >= 2 (smoe_test.py:36-37)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(6, val_iter=3)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4, lr_steer=0.01, quantization_mode=mode,
+                         quantize_pis=True, bit_depths=tuple(kw["bit_depths"]), lower_bounds=tuple(kw["lower_bounds"]),
+                         upper_bounds=tuple(kw["upper_bounds"]))
+    p0 = o.init_params(tb, [2, 2])
+    pn, _, info = o.fit(p0, tb.reshape(4, -1, 1), o.block_coords((16, 16)), cfg, 6, val_iter=3, dtype=np.float32)
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k], rtol=1e-5, atol=2e-6), k
+    assert np.allclose([v for _, v in s.get_losses()], [float(np.mean(l)) for l in info["hist"]["loss"]], rtol=1e-5)
+    if mode >= 1:
+        assert s.qparams is not None and s.rparams is None
+    # a kernel whose pi rounds to 0 on the 10-bit lattice of [0, 2] is not counted (pis_mask = qpis > 0)
+    p = s.get_params()
+    p["pis"][0, 0] = 0.0004
+    s2 = Smoe(img, init_params=p, batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
+    s2.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    assert s2.run_batched(train=False)[2] == 15
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_shared_facade_with_fake_quantised_variables(mode):
+    """SharedSmoe with quantize_pis / quantization_mode 2 (smoe.py:474-496) follows oracle.shared_fit; modes 1 and 3
+    are refused in this mode."""
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(32, 48, seed=6)
+    kw = dict(quantization_mode=mode, quantize_pis=True, bit_depths=[14, 12, 8, 10, 10],
+              lower_bounds=[-60, -.3, -1, 0, -4], upper_bounds=[60, 1.3, 2, 2, 4])
+    s = SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True,
+                   engine_factory=OracleSharedEngine, **kw)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(6, val_iter=3)
+    p0 = o.shared_init_params(img, [3, 4])
+    coords = o.global_batch_coords((32, 48), (16, 16))
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=12, lr_steer=0.01, quantization_mode=mode,
+                         quantize_pis=True, bit_depths=tuple(kw["bit_depths"]), lower_bounds=tuple(kw["lower_bounds"]),
+                         upper_bounds=tuple(kw["upper_bounds"]))
+    pn, _, info = o.shared_fit(p0, tb.reshape(6, -1, 1), coords, cfg, 6, val_iter=3, dtype=np.float32)
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
+    assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
+    for bad in (1, 3):
+        with pytest.raises(NotImplementedError):
+            SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], engine_factory=OracleSharedEngine,
+                       quantization_mode=bad)

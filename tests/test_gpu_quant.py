@@ -1,0 +1,184 @@
+"""GPU parity of the fake-quantised graph (quantize_pis and quantization_mode 2 / 3; smoe.py:474-538, SURVEY
+8(f-3)) against the CPU restatement (oracle.quantize_graph_params / route_quant_grads, themselves checked
+against torch.autograd through fake_quant_with_min_max_{args,vars} in tests/test_oracle.py).  Both sides
+quantise the variables with the same fp32 formula, so the lattice values are identical and the usual
+single-pass tolerances apply."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import smoe_oracle as o
+from test_gpu_parity import _bits_to_mask, _close, _engine, _mask_to_bits, _planar, _setup, _to_dev, _to_host
+
+pytestmark = pytest.mark.gpu
+
+QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), upper_bounds=(60, 1.3, 2, 2, 4))
+MODES = [(0, True), (2, True), (3, True)]
+QSHAPES = [
+    ((16, 16), 1, [2, 2], False),
+    ((16, 16), 3, [2, 2], True),
+    ((32, 32), 3, [2, 4], True),
+    ((16, 16, 4), 3, [2, 2, 1], True),
+]
+
+
+def _special(p):
+    # the A_corr variable is zero on and above the diagonal (initialised so, and no gradient ever reaches those
+    # entries); mode 3 takes its range over the whole matrices, i.e. 0 is always inside
+    d = p["A_corr"].shape[-1]
+    p["A_corr"] = p["A_corr"] * np.tril(np.ones((d, d), np.float32), -1)
+    p["pis"][1, 0] = 0.0006          # rounds to 0 on the 10-bit lattice of [0, 2]: the kernel is absent
+    p["pis"][2, 1] = 2.4             # clamped to 2, no gradient
+    p["musX"][3, 1, 0] = 1.32        # outside the fixed musX range of mode 2
+    p["A_corr"][4, 0, 1, 0] = 75.0   # outside the fixed A range of mode 2; the new max of mode 3
+    return p
+
+
+@pytest.mark.parametrize("mode,qpis", MODES)
+@pytest.mark.parametrize("shape,C,kpd,yuv", QSHAPES)
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_quant_forward(shape, C, kpd, yuv, mode, qpis, tiling):
+    B = 23
+    kw = dict(quantization_mode=mode, quantize_pis=qpis, **QKW)
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 60 + C + mode, pis_l1=0.2, u_l1=0.003, **kw)
+    p = _special(p)
+    active = np.random.default_rng(2).uniform(size=(B, K)) < 0.9
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.2, u_l1=0.003, **kw)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    out = eng.forward(_planar(tgt), dp, act, want_recon=True, want_gate=True)
+    torch.cuda.synchronize()
+    gate = out["gate_w"].cpu().numpy()
+    near_tau = np.abs(ref["w"] - 0.5 / 256) < 1e-6
+    assert (_close(gate, ref["wt"]) | near_tau).all(), np.abs(gate - ref["wt"]).max()
+    assert not gate[1, 0].any() and not ref["wt"][1, 0].any()            # qpis = 0
+    recon = np.transpose(out["recon"].cpu().numpy(), (0, 2, 1))
+    frac = (np.clip(ref["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie = (frac < 3e-4) | (frac > 1 - 3e-4)
+    assert (np.abs(recon - ref["recon"])[~tie] < 1e-7).all()
+    refq = o.forward(p, tgt, coords, active, cfg, None, np.float32, q_override=recon)
+    assert _close(out["loss"].cpu().numpy(), refq["loss"], rtol=2e-5).all()
+    assert _close(out["sse"].cpu().numpy(), refq["sse"], rtol=2e-5).all()
+    new_act = _bits_to_mask(act.cpu().numpy().view(np.uint32), K)
+    assert (new_act == ref["active_new"])[~near_tau.any(axis=2)].all()
+    eng.close()
+
+
+@pytest.mark.parametrize("mode,qpis", MODES)
+@pytest.mark.parametrize("shape,C,kpd,yuv", QSHAPES)
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_quant_one_step_gradients(shape, C, kpd, yuv, mode, qpis, tiling):
+    B = 21
+    kw = dict(quantization_mode=mode, quantize_pis=qpis, **QKW)
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 300 + C + mode, pis_l1=0.05, u_l1=0.001, **kw)
+    p = _special(p)
+    active = np.ones((B, K), dtype=bool)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.05, u_l1=0.001, **kw)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True, q_override=recon)
+    state = eng.new_adam_state(dp)
+    loss = torch.zeros(B, device="cuda")
+    eng.fit(T, dp, state, act, 1, loss_out=loss)
+    torch.cuda.synchronize()
+    tie = (np.abs(ref["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    edge = ((np.abs(ref["y"]) < 1e-6) | (np.abs(ref["y"] - 1) < 1e-6)).any(axis=(1, 2))
+    clean = ~(tie | edge)
+    assert clean.sum() >= B // 2
+    assert _close(loss.cpu().numpy()[clean], ref["loss"][clean], rtol=2e-5).all()
+    m = _to_host(state.m)
+    for name in o.PARAM_NAMES:
+        g_ref = ref["grads"][name][clean]
+        scale = np.abs(g_ref).max() + 1e-30
+        err = np.abs(m[name][clean] / 0.1 - g_ref).max() / scale
+        assert err < 5e-5, (name, err)
+    # the masked / routed elements specifically
+    assert m["pis"][2, 1] == 0.0 and m["pis"][1, 0] == 0.0
+    if mode == 2:
+        assert m["musX"][3, 1, 0] == 0.0 and m["A_corr"][4, 0, 1, 0] == 0.0
+    if mode == 3:
+        assert np.abs(ref["grads"]["musX"] - o.forward(p, tgt, coords, active,
+                      o.OracleConfig(**{**cfg.__dict__, "quantization_mode": 0}), None, np.float32, want_grads=True,
+                      q_override=recon)["grads"]["musX"]).max() > 0      # mode 3 really changes / routes the gradients
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_quant_short_fit_and_readmission(mode):
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 40
+    kw = dict(quantization_mode=mode, quantize_pis=True, **QKW)
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 991, perturb=False, lr_steer=1e-2, **kw)
+    n = 12
+    p32, _, i32 = o.fit(p, tgt, coords, cfg, n, val_iter=6, dtype=np.float32)
+    eng = _engine(shape, C, K, lr_steer=1e-2, **kw)
+    dp = _to_dev(p)
+    state = eng.new_adam_state(dp)
+    act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
+    T = _planar(tgt)
+    l0 = eng.forward(T, dp, act, want_recon=False)["loss"].cpu().numpy()
+    hist = [l0]
+    for _ in range(2):
+        eng.fit(T, dp, state, act, 6)
+        eng.update_kernel_list(dp, act)
+        hist.append(eng.forward(T, dp, act, want_recon=False)["loss"].cpu().numpy())
+    torch.cuda.synchronize()
+    assert np.allclose(hist[0], i32["hist"]["loss"][0], rtol=2e-5, atol=1e-9)
+    # 12 gentle steps: the trajectories agree closely for most blocks (a parameter crossing a lattice point
+    # a step earlier or later shows up as an outlier, hence quantiles)
+    got = _to_host(dp)
+    for name in o.PARAM_NAMES:
+        dev = np.abs(got[name] - p32[name]).reshape(B, -1).max(axis=1)
+        lr = {"pis": 1e-5, "A_diagonal": 1e-2, "A_corr": 1e-2}.get(name, 1e-3)
+        assert np.quantile(dev, 0.7) <= 0.05 * lr * n + 1e-6, (name, np.quantile(dev, 0.7))
+    assert np.median(np.abs(hist[2] - i32["hist"]["loss"][2]) / i32["hist"]["loss"][2]) < 1e-3
+    # readmission alone: empty lists, far kernels and quantised-away pis stay out
+    pp = {k: v.copy() for k, v in got.items()}
+    pp["A_diagonal"][5] *= 40.0
+    pp["pis"][7, 2] = 0.0005
+    want = o.readmit(pp, np.zeros((B, K), bool), cfg, np.float32)
+    empty = torch.zeros_like(act)
+    eng.update_kernel_list(_to_dev(pp), empty)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits_to_mask(empty.cpu().numpy().view(np.uint32), K), want)
+    assert not want[7, 2]
+    eng.close()
+
+
+def test_quant_facade_on_gpu_follows_the_oracle_backed_facade():
+    from fake_engine import OracleEngine
+    from steered_mixture_of_experts_amd import blocks as blk
+    from steered_mixture_of_experts_amd.smoe import Adam, Smoe
+    b = blk.synthetic_blocks(16, (16, 16), 1, 5)
+    img = blk.blocks_to_image(b, (64, 64), (16, 16))
+    for mode in (0, 3):
+        runs = []
+        for factory in (None, OracleEngine):
+            s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=mode,
+                     quantize_pis=True, bit_depths=list(QKW["bit_depths"]), lower_bounds=list(QKW["lower_bounds"]),
+                     upper_bounds=list(QKW["upper_bounds"]), **({} if factory is None else {"engine_factory": factory}))
+            s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+            s.train(12, val_iter=6)
+            runs.append(([v for _, v in s.get_losses()], s.get_num_pis()))
+        (lg, ng), (lo, no) = runs
+        assert abs(lg[0] - lo[0]) < 1e-6 * lo[0] + 1e-9 and np.allclose(lg, lo, rtol=2e-2)
+        assert ng == no
+
+
+def test_quant_configuration_errors():
+    from steered_mixture_of_experts_amd import _lib
+    from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
+    with pytest.raises(_lib.SmoeError) as e:
+        BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantization_mode=5))
+    assert e.value.code == _lib.SMOE_ERR_INVALID
+    with pytest.raises(_lib.SmoeError) as e:
+        BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantization_mode=2, ssim_opt=True))
+    assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
+    with pytest.raises(_lib.SmoeError):
+        BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantize_pis=True, bit_depths=(20, 18, 6, 30, 10)))

@@ -274,3 +274,58 @@ def test_shared_overlap_halo(shape, bshape, C, kpd, ov):
     assert (_mask(dl2.cpu().numpy().view(np.uint32), K) == info["lists"]).mean() > 0.98
     for e in (eng, eng0, eng2):
         e.close()
+
+
+QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), upper_bounds=(60, 1.3, 2, 2, 4))
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("shape,bshape,C,kpd,yuv", [CASES[0], CASES[1], CASES[3]])
+def test_shared_fake_quantised_variables(shape, bshape, C, kpd, yuv, mode):
+    """quantize_pis / quantization_mode 2 in the shared-kernel mode (smoe.py:474-496): forward, accumulated
+    gradients through the straight-through masks, one Adam step, readmission on the quantised variables."""
+    kw = dict(quantization_mode=mode, quantize_pis=True, **QKW)
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, pis_l1=0.05, u_l1=0.001, **kw)
+    d = len(shape)
+    p["A_corr"] = p["A_corr"] * np.tril(np.ones((d, d), np.float32), -1)
+    p["pis"][0, 1] = 0.0006            # rounds to 0 on the lattice: kernel absent
+    p["pis"][0, 2] = 2.3               # clamped, no gradient
+    p["musX"][0, 3, 0] = 1.31          # outside the fixed musX range (mode 2)
+    lists = np.ones((NB, K), bool)
+    ref = o.shared_pass(p, tgt, coords, lists, cfg, np.float32)
+    eng = _engine(shape, bshape, C, K, yuv, pis_l1=0.05, u_l1=0.001, **kw)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True, update_lists=False)
+    torch.cuda.synchronize()
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    frac = (np.clip(ref["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie = (frac < 3e-4) | (frac > 1 - 3e-4)
+    assert (np.abs(recon - ref["recon"])[~tie] < 1e-7).all()
+    f32 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float32, want_grads=True, q_override=recon)
+    g32 = {k: v.sum(axis=0) for k, v in f32["grads"].items()}
+    assert np.allclose(fw["loss"].cpu().numpy(), f32["loss"], rtol=3e-5)
+    st = eng.new_adam_state(dp)
+    eng.accumulate(T, dp, dl)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    bad = (np.abs(f32["w"] - 0.5 / 256) < 1e-6).any() or ((np.abs(f32["y"]) < 1e-6) | (np.abs(f32["y"] - 1) < 1e-6)).any()
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g32[name]).max() + 1e-30
+        err = np.abs(st.m[name].cpu().numpy() / 0.1 - g32[name]).max() / scale
+        assert err < (2e-3 if bad else 5e-5), (name, err)
+    m = {k: v.cpu().numpy() for k, v in st.m.items()}
+    assert m["pis"][1] == 0.0 and m["pis"][2] == 0.0
+    if mode == 2:
+        assert m["musX"][3, 0] == 0.0
+    empty = torch.zeros_like(dl)
+    got = {k: v.cpu().numpy()[None] for k, v in dp.items()}
+    eng.update_kernel_list(dp, empty)
+    want = o.shared_readmit(got, np.zeros((NB, K), bool), coords, cfg, np.float32)
+    assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want) and not want[:, 1].any()
+    eng.close()
+    from steered_mixture_of_experts_amd import _lib
+    with pytest.raises(_lib.SmoeError) as e:
+        _engine(shape, bshape, C, K, yuv, quantization_mode=3)
+    assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
