@@ -1,0 +1,1600 @@
+// smoe_block.cuh -- CDNA4 (gfx950) device templates of the per-block SMoE hot path: packed parameter layout, the
+// per-pixel forward / backward, the LDS tile, the fit and forward kernels with their SSIM and fake-quant
+// variants, and the launcher templates.  Included by one translation unit per (D, C, K) instantiation
+// (smoe_var_*.hip), which are compiled in parallel, and by smoe_kernels.hip (small kernels + the dispatch table).
+//
+// What one workgroup does: WAVES wavefronts, each wavefront owns 64/G image blocks
+// (G lanes per block, N/G pixels per lane).  The block's parameters live in LDS
+// (broadcast reads at the top of every iteration) and in registers during the pixel
+// loop; targets / coordinates are staged once per launch into LDS with coalesced HBM
+// reads; the K*P gradient sums are reduced across the G lanes through an LDS transpose
+// (every lane finishes ONE sum per pass: "owner" lanes), the owner applies TF1-Adam to
+// its parameter and publishes it back to LDS.  No inter-workgroup communication.
+//
+// Maths: SURVEY.md Appendix A; reference lines are cited at each step
+// (paths relative to /root/reference).
+#ifndef SMOE_BLOCK_CUH
+#define SMOE_BLOCK_CUH
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "smoe_device.h"
+
+namespace smoe {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS hand-off between lanes of ONE wavefront: DS ops of a wave execute in order,
+    // so only compiler ordering + completion of the stores is required.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// A value that is the same in every lane of the wavefront -> scalar register.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
+constexpr int tri_index(int l, int m) { return l * (l + 1) / 2 + m; }   // l >= m
+
+// Packed per-block parameter vector: for every kernel k
+//   [ pi | mu[0..D) | A lower-tri row-major (l>=m) | nu[0..C) | gamma[l][c] ]
+// Gradient sums use the same indexing ("slot j <-> packed parameter j"); three kinds
+// of extra slots follow: loss, sse, and the K influence counters (smoe.py:829).
+template <int D, int C, int K>
+struct Layout {
+    static constexpr int TRI = D * (D + 1) / 2;
+    static constexpr int O_PI = 0;
+    static constexpr int O_MU = 1;
+    static constexpr int O_A = 1 + D;
+    static constexpr int O_NU = O_A + TRI;
+    static constexpr int O_GA = O_NU + C;
+    static constexpr int PK = O_GA + D * C;
+    static constexpr int NPAR = K * PK;
+    static constexpr int S_LOSS = NPAR;
+    static constexpr int S_SSE = NPAR + 1;
+    static constexpr int S_CNT = NPAR + 2;
+    static constexpr int NSLOT = NPAR + 2 + K;
+    // LDS image of one block: packed params, K active flags, frozen flag
+    static constexpr int LP_ACT = NPAR;
+    static constexpr int LP_FROZEN = NPAR + K;
+    static constexpr int LP_STRIDE = round_up(NPAR + K + 1, 4);
+};
+
+// Where packed parameter j of block b lives in the reference's tensors
+// (get_params layout, smoe.py:1795-1800).  tensor: 0 pis 1 musX 2 A_diagonal 3 A_corr
+// 4 gamma_e 5 nu_e.
+template <int D, int C, int K>
+__device__ __forceinline__ void decode_slot(int j, int b, int& tensor, long& off, int& kern) {
+    using Lt = Layout<D, C, K>;
+    const int k = j / Lt::PK;
+    const int o = j - k * Lt::PK;
+    const long bk = (long)b * K + k;
+    kern = k;
+    if (o == Lt::O_PI) {
+        tensor = 0; off = bk;
+    } else if (o < Lt::O_A) {
+        tensor = 1; off = bk * D + (o - Lt::O_MU);
+    } else if (o < Lt::O_NU) {
+        const int t = o - Lt::O_A;
+        int l = 0;
+        while ((l + 1) * (l + 2) / 2 <= t) ++l;
+        const int m = t - l * (l + 1) / 2;
+        tensor = (l == m) ? 2 : 3;
+        off = (bk * D + l) * D + m;
+    } else if (o < Lt::O_GA) {
+        tensor = 5; off = bk * C + (o - Lt::O_NU);
+    } else {
+        const int t = o - Lt::O_GA;     // l*C + c
+        tensor = 4; off = bk * (D * C) + t;
+    }
+}
+
+__device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
+    switch (tensor) {
+        case 0: return s.pis;
+        case 1: return s.musX;
+        case 2: return s.A_diagonal;
+        case 3: return s.A_corr;
+        case 4: return s.gamma_e;
+        default: return s.nu_e;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-pixel forward (+ optional backward accumulation)
+// ---------------------------------------------------------------------------
+// sqrt(0.5 * log2(e)): with A' = SQ * A, |A'^T r|^2 = maha * 0.5*log2(e), so
+// exp(-maha/2) = exp2(-|z'|^2) and the per-kernel scale multiply disappears.
+#define SMOE_SQ 0.84932180028801904272f
+#define SMOE_INV_SQ 1.17740022503374817543f
+
+template <int D, int C, int K>
+struct BlockRegs {
+    using Lt = Layout<D, C, K>;
+    float P[Lt::LP_STRIDE];   // packed params + flags, filled from LDS
+    float As[K][Lt::TRI];     // A' = SQ * A (lower triangle)
+    float cz[K][D];           // c = A'^T mu, so z' = A'^T x - c
+    float coef[K];            // pi * prod diag(A) / sqrt((2pi)^d), 0 when the kernel is inactive
+    // hoisting (HL = number of trailing coordinates that are the same for all pixels of the lane):
+    float hz[K][D];           // sum_{l>=D-HL} x_l A'[l][m] - c[m]   (z' = sum_{l<D-HL} x_l A'[l][m] + hz[m])
+    float he[K][C];           // nu + sum_{l>=D-HL} gamma[l] x_l      (e  = he + sum_{l<D-HL} gamma[l] x_l)
+
+    __device__ __forceinline__ float pi(int k) const { return P[k * Lt::PK + Lt::O_PI]; }
+    __device__ __forceinline__ float mu(int k, int l) const { return P[k * Lt::PK + Lt::O_MU + l]; }
+    __device__ __forceinline__ float A(int k, int l, int m) const { return P[k * Lt::PK + Lt::O_A + tri_index(l, m)]; }
+    __device__ __forceinline__ float nu(int k, int c) const { return P[k * Lt::PK + Lt::O_NU + c]; }
+    __device__ __forceinline__ float ga(int k, int l, int c) const { return P[k * Lt::PK + Lt::O_GA + l * C + c]; }
+    __device__ __forceinline__ bool flag(int k) const { return P[Lt::LP_ACT + k] != 0.0f; }
+    __device__ __forceinline__ bool frozen() const { return P[Lt::LP_FROZEN] != 0.0f; }
+    __device__ __forceinline__ bool act(int k) const { return flag(k) && (pi(k) > 0.0f); }
+
+    __device__ __forceinline__ void load(const float* __restrict__ lds_block) {
+        const float4* src = reinterpret_cast<const float4*>(lds_block);
+#pragma unroll
+        for (int i = 0; i < Lt::LP_STRIDE / 4; ++i) {
+            const float4 q = src[i];
+            P[4 * i + 0] = q.x; P[4 * i + 1] = q.y; P[4 * i + 2] = q.z; P[4 * i + 3] = q.w;
+        }
+    }
+
+    // smoe.py:480,738 (bool_mask = kernel_list & pis>0), 809-819 (determinant factor, * pis)
+    __device__ __forceinline__ void derive(const KernelConsts& kc) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float det = 1.0f;
+#pragma unroll
+            for (int l = 0; l < D; ++l) det *= A(k, l, l);
+            const float nq = kc.use_det ? det * kc.inv_n_dis : 1.0f;   // n_quo = n_div / n_dis (reciprocal from the host)
+            coef[k] = act(k) ? nq * pi(k) : 0.0f;
+#pragma unroll
+            for (int l = 0; l < D; ++l)
+#pragma unroll
+                for (int m = 0; m <= l; ++m) As[k][tri_index(l, m)] = SMOE_SQ * A(k, l, m);
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float c = 0.0f;
+#pragma unroll
+                for (int l = m; l < D; ++l) c = fmaf(mu(k, l), As[k][tri_index(l, m)], c);
+                cz[k][m] = c;
+            }
+            if (!kc.train_gammas) {          // smoe.py:841-848: the slopes are not part of the graph
+#pragma unroll
+                for (int i = 0; i < D * C; ++i) P[k * Lt::PK + Lt::O_GA + i] = 0.0f;
+            }
+            if (kc.only_y_gamma) {           // smoe.py:725-729: qgamma_e * gamma_mask (channel 0 only)
+#pragma unroll
+                for (int l = 0; l < D; ++l)
+#pragma unroll
+                    for (int c = 1; c < C; ++c) P[k * Lt::PK + Lt::O_GA + l * C + c] = 0.0f;
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Fake-quantised parameters (quantize_pis, quantization_mode 2 / 3; smoe.py:474-538): TF
+// fake_quant_with_min_max_{args,vars}.  Every lane holds all K kernels of its block, so the ranges of
+// mode 3 (min / max over the kernels with qpis > 0) need no cross-lane step.
+// ---------------------------------------------------------------------------
+struct FqRange {
+    float nmin, nmax, scale, inv, back;   // nudged range, step, 1/step, offset added back (x - min forms)
+    bool zero;                            // min == max == 0: TF outputs zeros and passes the whole gradient
+};
+
+__device__ __forceinline__ FqRange fq_fixed(const KernelConsts& kc, int g) {
+    FqRange r;
+    r.nmin = kc.q_nmin[g]; r.nmax = kc.q_nmax[g]; r.scale = kc.q_scale[g]; r.inv = kc.q_inv[g];
+    r.back = 0.0f; r.zero = false;
+    return r;
+}
+
+// TF Nudge() on [rmin, rmax] with levels = 2^bits - 1 (fake_quant_ops_functor.h), fp32 as on the device there
+__device__ __forceinline__ FqRange fq_vars(float lo, float hi, float levels, bool offset) {
+    FqRange r;
+    const float rmin = offset ? 0.0f : lo;
+    const float rmax = offset ? hi - lo : hi;
+    r.back = offset ? lo : 0.0f;
+    r.zero = (rmin == 0.0f) && (rmax == 0.0f);
+    r.scale = (rmax - rmin) / levels;
+    const float zp = 0.0f - rmin / r.scale;
+    const float nzp = (zp < 0.0f) ? 0.0f : ((zp > levels) ? levels : roundf(zp));
+    r.nmin = (0.0f - nzp) * r.scale;
+    r.nmax = (levels - nzp) * r.scale;
+    r.inv = 1.0f / r.scale;
+    return r;
+}
+
+__device__ __forceinline__ float fq_val(float x, const FqRange& r) {
+    const float v = x - r.back;
+    const float cl = fminf(fmaxf(v, r.nmin), r.nmax);
+    const float q = floorf((cl - r.nmin) * r.inv + 0.5f) * r.scale + r.nmin;
+    return (r.zero ? 0.0f : q) + r.back;
+}
+
+// Ranges of one block in mode 3 from its RAW packed parameters P (and the already quantised pis in qpi[]):
+// A_diagonal: offset form over the diagonals; A_corr: over the whole d x d matrices (the structural zeros
+// of the variable keep 0 inside the range); musX, gamma_e: plain; nu_e: offset form (smoe.py:497-530).
+template <int D, int C, int K>
+struct BlockRanges {
+    FqRange ad, ac, mu, nu, ga;
+    float lo[5], hi[5];     // 0 A_diag, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e (raw extremes, for the tie tests)
+    __device__ __forceinline__ void compute(const float* P, const bool (&keep)[K], const KernelConsts& kc) {
+        using Lt = Layout<D, C, K>;
+        constexpr float INF = __builtin_huge_valf();
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { lo[t] = INF; hi[t] = -INF; }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (!keep[k]) continue;
+            any = true;
+            const float* p = P + k * Lt::PK;
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                lo[2] = fminf(lo[2], p[Lt::O_MU + l]); hi[2] = fmaxf(hi[2], p[Lt::O_MU + l]);
+#pragma unroll
+                for (int m = 0; m <= l; ++m) {
+                    const float a = p[Lt::O_A + tri_index(l, m)];
+                    const int t = (l == m) ? 0 : 1;
+                    lo[t] = fminf(lo[t], a); hi[t] = fmaxf(hi[t], a);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) { lo[3] = fminf(lo[3], p[Lt::O_NU + c]); hi[3] = fmaxf(hi[3], p[Lt::O_NU + c]); }
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) { lo[4] = fminf(lo[4], p[Lt::O_GA + i]); hi[4] = fmaxf(hi[4], p[Lt::O_GA + i]); }
+        }
+        lo[1] = fminf(lo[1], 0.0f); hi[1] = fmaxf(hi[1], 0.0f);          // diagonal / upper entries of the A_corr variable
+        if (!any) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { lo[t] = 0.0f; hi[t] = 0.0f; }
+        }
+        ad = fq_vars(lo[0], hi[0], kc.q_levels[0], true);
+        ac = fq_vars(lo[1], hi[1], kc.q_levels[0], false);
+        mu = fq_vars(lo[2], hi[2], kc.q_levels[1], false);
+        nu = fq_vars(lo[3], hi[3], kc.q_levels[2], true);
+        ga = fq_vars(lo[4], hi[4], kc.q_levels[4], false);
+    }
+};
+
+// Replace the packed parameters P by the fake-quantised values the graph is built on.
+// FULL = false: only the pis (quantize_pis, the reference CLI default) -- a few instructions, kept as a
+// run-time branch in the default kernels; modes 2 / 3 live in their own instantiations (QUANT) so that their
+// register footprint does not reach the hot kernels.
+template <int D, int C, int K, bool FULL>
+__device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc) {
+    using Lt = Layout<D, C, K>;
+    if (kc.qpis) {
+        const FqRange r = fq_fixed(kc, 3);
+#pragma unroll
+        for (int k = 0; k < K; ++k) P[k * Lt::PK + Lt::O_PI] = fq_val(P[k * Lt::PK + Lt::O_PI], r);
+    }
+    if constexpr (!FULL) return;
+    if (kc.qmode == 2) {
+        const FqRange ra = fq_fixed(kc, 0), rm = fq_fixed(kc, 1), rn = fq_fixed(kc, 2), rg = fq_fixed(kc, 4);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float* p = P + k * Lt::PK;
+#pragma unroll
+            for (int l = 0; l < D; ++l) p[Lt::O_MU + l] = fq_val(p[Lt::O_MU + l], rm);
+#pragma unroll
+            for (int i = 0; i < Lt::TRI; ++i) p[Lt::O_A + i] = fq_val(p[Lt::O_A + i], ra);
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[Lt::O_NU + c] = fq_val(p[Lt::O_NU + c], rn);
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) p[Lt::O_GA + i] = fq_val(p[Lt::O_GA + i], rg);
+        }
+    } else if (kc.qmode == 3) {
+        bool keep[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) keep[k] = P[k * Lt::PK + Lt::O_PI] > 0.0f;     // pis_mask = qpis > 0
+        BlockRanges<D, C, K> br;
+        br.compute(P, keep, kc);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float* p = P + k * Lt::PK;
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                if (kc.q_musx) p[Lt::O_MU + l] = fq_val(p[Lt::O_MU + l], br.mu);
+#pragma unroll
+                for (int m = 0; m <= l; ++m)
+                    p[Lt::O_A + tri_index(l, m)] = fq_val(p[Lt::O_A + tri_index(l, m)], (l == m) ? br.ad : br.ac);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) p[Lt::O_NU + c] = fq_val(p[Lt::O_NU + c], br.nu);
+#pragma unroll
+            for (int i = 0; i < D * C; ++i) p[Lt::O_GA + i] = fq_val(p[Lt::O_GA + i], br.ga);
+        }
+    }
+}
+
+// Backward of the mode-3 fake-quant ops on this lane's partial gradients acc[] (linear, so it commutes with
+// the cross-lane sum): inside the nudged range the gradient passes; what falls below / above goes to the
+// min / max input and from there (reduce_min / reduce_max) to the extreme elements, split over ties.
+// (Fixed ranges -- pis, mode 2 -- are plain per-element masks and are applied by the slot owners on the
+// reduced totals.)  Praw: the block's RAW packed parameters.
+template <int D, int C, int K>
+__device__ __forceinline__ void route_quant_partials(const float* Praw, const KernelConsts& kc, float* __restrict__ acc) {
+    using Lt = Layout<D, C, K>;
+    if (kc.qmode == 3) {
+        bool keep[K];
+        const FqRange rp = fq_fixed(kc, 3);
+#pragma unroll
+        for (int k = 0; k < K; ++k) keep[k] = fq_val(Praw[k * Lt::PK + Lt::O_PI], rp) > 0.0f;
+        BlockRanges<D, C, K> br;
+        br.compute(Praw, keep, kc);
+        // per tensor t: sums of the gradients that fall below / above, tie counts at the raw extremes
+        float GL[5], GA[5], nlo[5], nhi[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { GL[t] = GA[t] = 0.0f; nlo[t] = nhi[t] = 0.0f; }
+        auto tensor_of = [](int o) {      // packed offset -> 0 A_diag, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e
+            if (o < Lt::O_A) return 2;
+            if (o < Lt::O_NU) {
+                const int t = o - Lt::O_A;
+                int l = 0;
+                while ((l + 1) * (l + 2) / 2 <= t) ++l;
+                return (t - l * (l + 1) / 2 == l) ? 0 : 1;
+            }
+            return (o < Lt::O_GA) ? 3 : 4;
+        };
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int o = Lt::O_MU; o < Lt::PK; ++o) {
+                const int j = k * Lt::PK + o;
+                const int t = tensor_of(o);
+                if (t == 2 && !kc.q_musx) continue;
+                const FqRange& r = (t == 0) ? br.ad : ((t == 1) ? br.ac : ((t == 2) ? br.mu : ((t == 3) ? br.nu : br.ga)));
+                const float x = Praw[j], v = x - r.back;
+                const bool below = !r.zero && (v < r.nmin), above = !r.zero && (v > r.nmax);
+                GL[t] += below ? acc[j] : 0.0f;
+                GA[t] += above ? acc[j] : 0.0f;
+                nlo[t] += (keep[k] && x == br.lo[t]) ? 1.0f : 0.0f;
+                nhi[t] += (keep[k] && x == br.hi[t]) ? 1.0f : 0.0f;
+                acc[j] = (below || above) ? 0.0f : acc[j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            GL[t] = GL[t] / fmaxf(nlo[t], 1.0f);
+            GA[t] = GA[t] / fmaxf(nhi[t], 1.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int o = Lt::O_MU; o < Lt::PK; ++o) {
+                const int j = k * Lt::PK + o;
+                const int t = tensor_of(o);
+                if (t == 2 && !kc.q_musx) continue;
+                const float x = Praw[j];
+                acc[j] += (keep[k] && x == br.lo[t]) ? GL[t] : 0.0f;
+                acc[j] += (keep[k] && x == br.hi[t]) ? GA[t] : 0.0f;
+            }
+        }
+    }
+}
+
+// (Measured dead end, kept as a note: with G == 64 the block's derived constants are wave-uniform and could live in
+// SGPRs, but VALU forms with an SGPR source issue at ~4.8 vs ~3.2 cycles and the readfirstlanes add ~100 instructions
+// per iteration: 32x32 / K=8 / C=3 went 63 -> 49 Gpx-it/s.)
+template <int D, int C, int K, int HL>
+__device__ __forceinline__ void hoist_const(BlockRegs<D, C, K>& R, const float (&xc)[D]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float h = -R.cz[k][m];
+#pragma unroll
+            for (int l = D - 1; l >= D - HL; --l)
+                if (l >= m) h = fmaf(xc[l], R.As[k][tri_index(l, m)], h);
+            R.hz[k][m] = h;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float h = R.nu(k, c);
+#pragma unroll
+            for (int l = D - HL; l < D; ++l) h = fmaf(R.ga(k, l, c), xc[l], h);
+            R.he[k][c] = h;
+        }
+    }
+}
+
+template <int D, int C, int K>
+struct PixelOut {
+    float wt[K];    // masked gate
+    float q[C];     // quantised reconstruction
+};
+
+// One pixel.  TRAIN: accumulate raw gradient sums into acc[] (layout = packed params,
+// "raw" meaning before the per-lane linear post-transform, see finish_partials):
+//   acc[pi_k]      += u_k                      u_k = dL/dlog g_k
+//   acc[mu_k,m]    += u_k z'_m                 z' = A'^T (x - mu)
+//   acc[A_k,l,m]   += u_k x_l z'_m             (x, not x - mu: corrected in finish_partials)
+//   acc[nu_k,c]    += wt_k G_c     acc[ga_k,l,c] += wt_k G_c x_l
+// The influence slot accumulates sum_n wt_k (> 0 iff some pixel passes the mask, smoe.py:829).
+// EXTG (ssim_opt): dL/dq of the pixel comes from the caller (gext[c], the SSIM adjoint) instead of the
+// margin loss; the clip / fake-quant straight-through mask is still applied here and the loss slot is
+// left to the caller.
+template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false>
+__device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
+                                      const float (&x)[D], const float (&t)[C], float lw,
+                                      float* __restrict__ acc, PixelOut<D, C, K>& o,
+                                      const float* __restrict__ gext = nullptr) {
+    using Lt = Layout<D, C, K>;
+    float z[K][D], g[K];
+    float S = 0.0f;
+    // smoe.py:777-782,796,807: z = A^T (x - mu) ; n = exp(-|z|^2 / 2)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float maha = 0.0f;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float zz = (HL > 0) ? R.hz[k][m] : -R.cz[k][m];
+#pragma unroll
+            for (int l = D - 1 - HL; l >= m; --l) zz = fmaf(x[l], R.As[k][tri_index(l, m)], zz);
+            z[k][m] = zz;
+            maha = (m == 0) ? zz * zz : fmaf(zz, zz, maha);
+        }
+        g[k] = R.coef[k] * fast_exp2(-maha);
+        S = (k == 0) ? g[k] : S + g[k];
+    }
+    // smoe.py:820-827: normalise, floor 1e-11, min-influence mask
+    const float inv = fast_rcp(fmaxf(S, 10e-12f));
+    float w[K], e[K][C], y[C];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        w[k] = g[k] * inv;
+        o.wt[k] = (w[k] > kc.tau) ? w[k] : 0.0f;
+        acc[Lt::S_CNT + k] += o.wt[k];
+        // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float ee = (HL > 0) ? R.he[k][c] : R.nu(k, c);
+#pragma unroll
+            for (int l = 0; l < D - HL; ++l) ee = fmaf(R.ga(k, l, c), x[l], ee);
+            e[k][c] = ee;
+            y[c] = (k == 0) ? o.wt[k] * ee : fmaf(o.wt[k], ee, y[c]);
+        }
+    }
+    // smoe.py:857,899 (clip + fake quant), 905-937 (mse / margin loss)
+    float Gc[C];
+    float dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        // clip_by_value(0,1) then the fake-quant clamp to its nudged range: kc.nudged_max = min(1, nudged max)
+        const float yc = __builtin_amdgcn_fmed3f(y[c], 0.0f, kc.nudged_max);
+        o.q[c] = floorf(fmaf(yc, kc.inv_scale, 0.5f)) * kc.scale;
+        const float diff = o.q[c] - t[c];
+        const float ad = fabsf(diff) - kc.epsm;
+        acc[Lt::S_SSE] = fmaf(diff, diff, acc[Lt::S_SSE]);
+        const float cwl = kc.cw[c] * lw;
+        if (!EXTG) acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
+        if (TRAIN) {
+            // sign(diff) in {-1,0,1}: |diff| is either 0 or >= 2^-30, so diff * 2^100 saturates the clamp
+            const float sg = __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -1.0f, 1.0f);
+            const float gm = EXTG ? gext[c] : (cwl + cwl) * (ad * sg);
+            // clip_by_value / fake-quant straight-through: gradient only where neither clamp acted
+            Gc[c] = (yc == y[c]) ? gm : 0.0f;
+            dot = (c == 0) ? Gc[c] * y[c] : fmaf(Gc[c], y[c], dot);   // sum_k h_k w_k == sum_c G_c y_c
+        }
+    }
+    if (!TRAIN) return;
+    // ---- reverse pass, SURVEY Appendix A.4 (tf.gradients, smoe.py:1148) -------
+    // u_k = w_k (h_k - dot) with h_k = M_k (e_k.G)  ==  wt_k (e_k.G) - w_k dot ;
+    // when the normaliser sits on its 1e-11 floor it is a constant and the dot term drops.
+    dot = (S > 10e-12f) ? dot : 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float eg = e[k][0] * Gc[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) eg = fmaf(e[k][c], Gc[c], eg);
+        const float u = fmaf(o.wt[k], eg, -(w[k] * dot));
+        float* a = acc + k * Lt::PK;
+        a[Lt::O_PI] += u;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const float uz = u * z[k][m];
+            a[Lt::O_MU + m] += uz;
+#pragma unroll
+            for (int l = m; l < D - HL; ++l)               // hoisted rows l >= D-HL are x_l * sum(uz), done after the loop
+                a[Lt::O_A + tri_index(l, m)] = fmaf(x[l], uz, a[Lt::O_A + tri_index(l, m)]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float wg = o.wt[k] * Gc[c];
+            a[Lt::O_NU + c] += wg;
+#pragma unroll
+            for (int l = 0; l < D - HL; ++l)
+                a[Lt::O_GA + l * C + c] = fmaf(wg, x[l], a[Lt::O_GA + l * C + c]);
+        }
+    }
+}
+
+// Hoisting: complete the accumulators whose x factor is one of the lane-constant coordinates.
+template <int D, int C, int K, int HL>
+__device__ __forceinline__ void complete_const(const float (&xc)[D], float* __restrict__ acc) {
+    using Lt = Layout<D, C, K>;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float* a = acc + k * Lt::PK;
+#pragma unroll
+        for (int l = D - HL; l < D; ++l) {
+#pragma unroll
+            for (int m = 0; m <= l; ++m) a[Lt::O_A + tri_index(l, m)] = xc[l] * a[Lt::O_MU + m];
+#pragma unroll
+            for (int c = 0; c < C; ++c) a[Lt::O_GA + l * C + c] = xc[l] * a[Lt::O_NU + c];
+        }
+    }
+}
+
+// Per-lane linear post-transform of the raw partial sums into partial gradients (all maps
+// are linear in the sums and use block-uniform parameters, so they commute with the
+// cross-lane reduction).  With suz'_m = sum u z'_m (z' = SQ z) and sxz'_lm = sum u x_l z'_m:
+//   d/dpi   = (sum u) / pi
+//   d/dmu_l = sum_m A[l][m] suz_m                        (dm/dmu = -2 A z, dL/dm = -u/2)
+//   d/dA_lm = -(sxz_lm - mu_l suz_m) + [l==m, use_det] (sum u)/A_ll
+template <int D, int C, int K>
+__device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
+                                                float* __restrict__ acc) {
+    using Lt = Layout<D, C, K>;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float* a = acc + k * Lt::PK;
+        const bool act = R.act(k);
+        const float su = a[Lt::O_PI];
+        float suz[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) suz[m] = a[Lt::O_MU + m] * SMOE_INV_SQ;
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            float gm = 0.0f;
+#pragma unroll
+            for (int m = 0; m <= l; ++m) gm = fmaf(R.A(k, l, m), suz[m], gm);
+            a[Lt::O_MU + l] = gm;
+        }
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+#pragma unroll
+            for (int m = 0; m <= l; ++m) {
+                float v = fmaf(R.mu(k, l), suz[m], -(a[Lt::O_A + tri_index(l, m)] * SMOE_INV_SQ));
+                if (l == m && kc.use_det) v = fmaf(su, act ? fast_rcp(R.A(k, l, l)) : 0.0f, v);
+                a[Lt::O_A + tri_index(l, m)] = v;
+            }
+        }
+        a[Lt::O_PI] = su * (act ? fast_rcp(R.pi(k)) : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS carve-up shared by the fit and forward kernels
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES>
+struct Tile {
+    using Lt = Layout<D, C, K>;
+    static constexpr int BPW = 64 / G;                  // blocks per wavefront
+    static constexpr int NB = WAVES * BPW;              // blocks per workgroup
+    static constexpr int CH = (G == 16) ? 16 : 32;      // slots reduced per pass
+    static constexpr int ROW = 64 + 4;                  // padded row (bank-conflict-free b128 reads)
+    static constexpr int NCHUNK = (Lt::NSLOT + CH - 1) / CH;
+    static constexpr int SPL = (Lt::NSLOT + G - 1) / G; // owned slots per lane
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int MV_STRIDE = round_up(2 * Lt::NPAR, 4);   // Adam m,v image of one block
+
+    // float offsets inside dynamic LDS
+    // CR = coordinate rows staged in LDS (D, or D - HL when the trailing HL axes are hoisted)
+    __host__ __device__ static int off_coords() { return 0; }
+    __host__ __device__ static int off_par(int N, int CR) { return round_up(CR * N, 4); }
+    __host__ __device__ static int off_mv(int N, int CR) { return off_par(N, CR) + NB * Lt::LP_STRIDE; }
+    __host__ __device__ static int off_scratch(int N, int CR) { return off_mv(N, CR) + NB * MV_STRIDE; }
+    __host__ __device__ static int off_tgt(int N, int CR) { return off_scratch(N, CR) + WAVES * CH * ROW; }
+    __host__ __device__ static int off_lw(int N, int CR) { return off_tgt(N, CR) + NB * C * N; }
+    __host__ __device__ static size_t bytes(int N, bool has_lw, int CR = D) {
+        return sizeof(float) * (size_t)(off_lw(N, CR) + (has_lw ? NB * N : 0));
+    }
+    // ssim_opt (G == 64, one block per wavefront): the two tap tables of the workgroup, then per wavefront
+    // the planes X [C][N] (quantised reconstruction -> dL/dq), Wa [5][N] (column sums of x, x^2, xy, y, y^2;
+    // later the row pass of the adjoint) and Wb [3][N] (coefficient maps)
+    __host__ __device__ static int off_ssim(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * N : 0), 4); }
+    // G == 16 (16x16 blocks only): the SSIM stage runs in registers (ssim_block16), LDS holds just X per block
+    __host__ __device__ static int ssim_tabs(int bh, int bw) { return (G == 16) ? 0 : round_up(11 * (bh + bw), 4); }
+    __host__ __device__ static int ssim_wave(int N) { return (G == 16) ? BPW * C * N : round_up(C * N + 8 * N, 4); }
+    __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw) {
+        return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR) + ssim_tabs(bh, bw) + WAVES * ssim_wave(N));
+    }
+};
+
+template <int D, int C, int K, int G, int WAVES, int CR = D>
+__device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, const float* __restrict__ target,
+                                             const float* __restrict__ loss_w, int B, int N, int blk0,
+                                             float* __restrict__ lds) {
+    using T = Tile<D, C, K, G, WAVES>;
+    float* s_coords = lds + T::off_coords();
+    float* s_tgt = lds + T::off_tgt(N, CR);
+    float* s_lw = lds + T::off_lw(N, CR);
+    for (int i = threadIdx.x; i < CR * N; i += T::THREADS) s_coords[i] = coords[i];
+    const int per = C * N;
+    for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) {
+        const int lb = i / per;
+        const int rem = i - lb * per;
+        const int b = min(blk0 + lb, B - 1);
+        s_tgt[i] = target[(size_t)b * per + rem];
+    }
+    if (loss_w != nullptr) {
+        for (int i = threadIdx.x; i < T::NB * N; i += T::THREADS) {
+            const int lb = i / N;
+            const int rem = i - lb * N;
+            const int b = min(blk0 + lb, B - 1);
+            s_lw[i] = loss_w[(size_t)b * N + rem];
+        }
+    }
+}
+
+// Cross-lane reduction of acc[FIRST..NSLOT) over the G lanes of a block through an LDS
+// transpose: lane `sub` ends up with the totals of its slots sub, sub+G, ... in total[].
+// Pass c moves slots [c*CH, (c+1)*CH): every lane stores its partials of these slots as
+// rows (conflict-free 4-byte stores), then the owner of each row sums its G entries with
+// 16-byte reads (rows are padded by 4 floats so the b128 reads do not conflict).
+template <int D, int C, int K, int G, int WAVES, int FIRST>
+__device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, float* __restrict__ scratch_wave,
+                                             int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
+    using T = Tile<D, C, K, G, WAVES>;
+    using Lt = Layout<D, C, K>;
+    const int grp = lane / G;
+    const int sub = lane - grp * G;
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) total[s] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < T::NCHUNK; ++c) {
+        if ((c + 1) * T::CH <= FIRST) continue;            // compile-time: nothing wanted in this pass
+#pragma unroll
+        for (int a = 0; a < T::CH; ++a) {
+            const int j = c * T::CH + a;
+            if (j >= FIRST && j < Lt::NSLOT) scratch_wave[a * T::ROW + lane] = acc[j];
+        }
+        wave_lds_sync();
+        {
+            constexpr int dummy = 0; (void)dummy;
+            const int s = (c * T::CH) / G;                  // which of the lane's slots lives in this pass
+            const int h = c - s * (G / T::CH);              // which CH-wide group of lanes owns rows now
+            const int a = sub - h * T::CH;
+            const int j = c * T::CH + a;
+            if (a >= 0 && a < T::CH && j >= FIRST && j < Lt::NSLOT) {
+                const float4* row = reinterpret_cast<const float4*>(scratch_wave + a * T::ROW + grp * G);
+                float4 sum = row[0];
+#pragma unroll
+                for (int i = 1; i < G / 4; ++i) {
+                    const float4 q = row[i];
+                    sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+                }
+                const float tot = (sum.x + sum.y) + (sum.z + sum.w);
+#pragma unroll
+                for (int ss = 0; ss < T::SPL; ++ss)
+                    if (ss == s) total[ss] = tot;
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SSIM loss stage (ssim_opt; smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d blocks.
+// One wavefront works on one block-channel plane held in LDS.  The reference pads the block SYMMETRIC
+// by 5 (smoe.py:993-996) and correlates with the 11x11 Gaussian (sigma 1.5, VALID): per axis that is
+// the b x b matrix  T[i][j] = sum_a g[a] * [mirror(i + a - 5) == j]  (symmetric, band |i - j| <= 5,
+// built on the host), so the window statistic is  Tr * plane * Tc  and its adjoint is the same
+// product on the coefficient maps -- no padded copy, no scatter.
+// ---------------------------------------------------------------------------
+constexpr float SSIM_C1 = 0.0001f;    // (0.01 * max_val)^2   image_ops_impl.py:74,110
+constexpr float SSIM_C2 = 0.0009f;    // (0.03 * max_val)^2   image_ops_impl.py:75,111
+
+// Walk of the outputs n = lane, lane + 64, ... of one plane as (row i, column j) without a division per step.
+struct SsimWalk {
+    int i, j, di, dj;      // current position; per-step increments 64 / bw and 64 % bw
+    __device__ __forceinline__ SsimWalk(int lane, int bw) : i(lane / bw), j(lane - (lane / bw) * bw), di(64 / bw), dj(64 % bw) {}
+    __device__ __forceinline__ void next(int bw) {
+        j += dj; i += di;
+        if (j >= bw) { j -= bw; i += 1; }
+    }
+};
+
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+// Tap tables are banded: Tb[i][a] = T[i][i + a - 5], zero where i + a - 5 leaves the axis, so a tap is
+// weight * plane[clamp(i + a - 5)] with no compare / select.
+// dst[p][i][j] = sum_r Tr[i][r] * f_p(r, j): window sums along axis 0 of x, x^2, x*y, y, y^2
+__device__ __forceinline__ void ssim_cols_products(float* __restrict__ dst, const float* __restrict__ xp,
+                                                   const float* __restrict__ yp, const float* __restrict__ Trb,
+                                                   int bh, int bw, int N, int lane) {
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Trb + w.i * 11;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int o = clampi(w.i + a - 5, bh - 1) * bw + w.j;
+            const float wt = tw[a];
+            const float xv = xp[o], yv = yp[o];
+            const float wx = wt * xv, wy = wt * yv;
+            s0 += wx;
+            s1 = fmaf(wx, xv, s1);
+            s2 = fmaf(wx, yv, s2);
+            s3 += wy;
+            s4 = fmaf(wy, yv, s4);
+        }
+        dst[n] = s0;
+        dst[N + n] = s1;
+        dst[2 * N + n] = s2;
+        dst[3 * N + n] = s3;
+        dst[4 * N + n] = s4;
+    }
+}
+
+// dst[p][i][j] = sum_c Tc[j][c] * src[p][i][c]
+template <int NP>
+__device__ __forceinline__ void ssim_rows(float* __restrict__ dst, const float* __restrict__ src,
+                                          const float* __restrict__ Tcb, int bw, int N, int lane) {
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Tcb + w.j * 11;
+        const int row = w.i * bw;
+        float s[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int o = row + clampi(w.j + a - 5, bw - 1);
+            const float wt = tw[a];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) s[p] = fmaf(wt, src[p * N + o], s[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dst[p * N + n] = s[p];
+    }
+}
+
+// Row pass of the five sums + the SSIM formula per window position (image_ops_impl.py:110-129).
+// Returns this lane's sum of luminance * contrast-structure; with GRAD the three coefficient maps
+// scale * d(l*cs)/d{mu_x, E[x^2], E[xy]} go to dst.
+template <bool GRAD>
+__device__ __forceinline__ float ssim_rows_stats(float* __restrict__ dst, const float* __restrict__ src,
+                                                 const float* __restrict__ Tcb, int bw, int N, int lane, float scale) {
+    float part = 0.0f;
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Tcb + w.j * 11;
+        const int row = w.i * bw;
+        float mx = 0.0f, sx = 0.0f, pxy = 0.0f, my = 0.0f, sy = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int o = row + clampi(w.j + a - 5, bw - 1);
+            const float wt = tw[a];
+            mx = fmaf(wt, src[o], mx);
+            sx = fmaf(wt, src[N + o], sx);
+            pxy = fmaf(wt, src[2 * N + o], pxy);
+            my = fmaf(wt, src[3 * N + o], my);
+            sy = fmaf(wt, src[4 * N + o], sy);
+        }
+        const float num0 = mx * my * 2.0f;
+        const float den0 = mx * mx + my * my;
+        const float N0 = num0 + SSIM_C1, D0 = den0 + SSIM_C1;
+        const float N1 = (pxy * 2.0f - num0) + SSIM_C2;
+        const float D1 = ((sx + sy) - den0) + SSIM_C2;
+        const float r0 = 1.0f / D0, r1 = 1.0f / D1;
+        const float lum = N0 * r0, cs = N1 * r1;
+        part = fmaf(lum, cs, part);
+        if (GRAD) {
+            const float dl = (2.0f * my - lum * (2.0f * mx)) * r0;             // d lum / d mu_x
+            const float dc = (cs * (2.0f * mx) - 2.0f * my) * r1;              // d cs / d mu_x
+            dst[n] = scale * fmaf(cs, dl, lum * dc);
+            dst[N + n] = scale * (-(lum * cs) * r1);                            // d / d E[x^2]
+            dst[2 * N + n] = scale * ((lum + lum) * r1);                        // d / d E[xy]
+        }
+    }
+    return part;
+}
+
+// Column pass of the adjoint + assembly of dL/dq:  g = Ga + 2 x Gb + y Gc, written over x in place.
+__device__ __forceinline__ void ssim_cols_adjoint(float* __restrict__ xp, const float* __restrict__ yp,
+                                                  const float* __restrict__ src, const float* __restrict__ Trb,
+                                                  int bh, int bw, int N, int lane) {
+    SsimWalk w(lane, bw);
+    for (int n = lane; n < N; n += 64, w.next(bw)) {
+        const float* tw = Trb + w.i * 11;
+        float ga = 0.0f, gb = 0.0f, gc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 11; ++a) {
+            const int o = clampi(w.i + a - 5, bh - 1) * bw + w.j;
+            const float wt = tw[a];
+            ga = fmaf(wt, src[o], ga);
+            gb = fmaf(wt, src[N + o], gb);
+            gc = fmaf(wt, src[2 * N + o], gc);
+        }
+        const float xv = xp[n];
+        xp[n] = fmaf(yp[n], gc, fmaf(xv + xv, gb, ga));
+    }
+}
+
+// 1 - SSIM of one block: returns this lane's share of -sum_c sw_c * mean(l * cs); with GRAD the plane
+// X[c] is replaced by dL/dq.  sw[c] = channel weight / window count (kc.sw).
+template <int C, bool GRAD>
+__device__ __forceinline__ float ssim_block(float* __restrict__ X, const float* __restrict__ tgt,
+                                            float* __restrict__ wa, float* __restrict__ wb,
+                                            const float* __restrict__ Tr, const float* __restrict__ Tc,
+                                            const float* __restrict__ sw, int bh, int bw, int N, int lane) {
+    float part = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        float* xp = X + c * N;
+        const float* yp = tgt + c * N;
+        ssim_cols_products(wa, xp, yp, Tr, bh, bw, N, lane);
+        wave_lds_sync();
+        const float swc = (c == 0) ? sw[0] : ((c == 1) ? sw[1] : sw[2]);   // no dynamic indexing of kernel arguments
+        part -= swc * ssim_rows_stats<GRAD>(wb, wa, Tc, bw, N, lane, -swc);
+        if (GRAD) {
+            wave_lds_sync();
+            ssim_rows<3>(wa, wb, Tc, bw, N, lane);
+            wave_lds_sync();
+            ssim_cols_adjoint(xp, yp, wa, Tr, bh, bw, N, lane);
+        }
+        wave_lds_sync();
+    }
+    return part;
+}
+
+// ---------------------------------------------------------------------------
+// SSIM stage for 16x16 blocks on the 16-lanes-per-block tiling, entirely in registers: lane `sub` of a
+// block owns image column `sub` (pixels n = i*16 + sub), so
+//   * the column pass (axis 0) is in-lane: out[i] = sum_r T16[i][r] in[r] with COMPILE-TIME weights
+//     (the 16x16 tap matrix is folded to literals, zero taps vanish);
+//   * the row pass (axis 1) is across the 16 lanes of the block = one DPP row: eleven row_shl / row_shr
+//     shifted operands (bound_ctrl: lanes outside the row read 0) times per-lane weights
+//     wj[a] = T16[sub][sub + a - 5].
+// No LDS traffic besides reading q / target and writing dL/dq, no barriers.
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr float ssim_gauss(int a) {      // image_ops_impl.py:132-149, size 11, sigma 1.5
+    constexpr float g[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.6000773311e-02f, 1.0936068743e-01f,
+                             2.1300554276e-01f, 2.6601171494e-01f, 2.1300554276e-01f, 1.0936068743e-01f,
+                             3.6000773311e-02f, 7.5987582095e-03f, 1.0283801239e-03f};
+    return g[a];
+}
+__host__ __device__ constexpr float ssim_t16(int i, int r) {  // SYMMETRIC pad 5 + 11 taps on a 16-sample axis
+    float s = 0.0f;
+    for (int a = 0; a < 11; ++a) {
+        int m = i + a - 5;
+        if (m < 0) m = -1 - m;
+        if (m >= 16) m = 31 - m;
+        if (m == r) s += ssim_gauss(a);
+    }
+    return s;
+}
+
+template <int NQ>
+__device__ __forceinline__ void ssim_colpass16(const float (&in)[NQ][16], float (&out)[NQ][16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) out[q][i] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float w = ssim_t16(i, r);
+            if (w != 0.0f) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) out[q][i] = fmaf(w, in[q][r], out[q][i]);
+            }
+        }
+    }
+}
+
+// value of lane (L + SH) of the same 16-lane row, 0 when that lane is outside the row
+template <int SH>
+__device__ __forceinline__ float ssim_row_neighbour(float v) {
+    constexpr int ctrl = (SH > 0) ? (0x100 + SH) : (0x110 - SH);   // row_shl:SH / row_shr:-SH
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float ssim_rowpass16(float v, const float (&wj)[11]) {
+    float s = wj[5] * v;
+    s = fmaf(wj[6], ssim_row_neighbour<1>(v), s);
+    s = fmaf(wj[4], ssim_row_neighbour<-1>(v), s);
+    s = fmaf(wj[7], ssim_row_neighbour<2>(v), s);
+    s = fmaf(wj[3], ssim_row_neighbour<-2>(v), s);
+    s = fmaf(wj[8], ssim_row_neighbour<3>(v), s);
+    s = fmaf(wj[2], ssim_row_neighbour<-3>(v), s);
+    s = fmaf(wj[9], ssim_row_neighbour<4>(v), s);
+    s = fmaf(wj[1], ssim_row_neighbour<-4>(v), s);
+    s = fmaf(wj[10], ssim_row_neighbour<5>(v), s);
+    s = fmaf(wj[0], ssim_row_neighbour<-5>(v), s);
+    return s;
+}
+
+// Same contract as ssim_block for one 16x16 block handled by 16 lanes: X [C][256] holds q and receives
+// dL/dq; returns the lane's share of -sum_c sw_c * sum(l * cs).
+template <int C, bool GRAD>
+__device__ __forceinline__ float ssim_block16(float* __restrict__ X, const float* __restrict__ tgt, int sub,
+                                              const float (&wj)[11], const float* __restrict__ sw) {
+    float part = 0.0f;
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        const float swc = (c == 0) ? sw[0] : ((c == 1) ? sw[1] : sw[2]);
+        float* xp = X + c * 256 + sub;
+        const float* yp = tgt + c * 256 + sub;
+        float in[5][16], v[5][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float xv = xp[i * 16], yv = yp[i * 16];
+            in[0][i] = xv; in[1][i] = xv * xv; in[2][i] = xv * yv; in[3][i] = yv; in[4][i] = yv * yv;
+        }
+        ssim_colpass16<5>(in, v);
+        float co[3][16];
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float mx = ssim_rowpass16(v[0][i], wj), sx = ssim_rowpass16(v[1][i], wj);
+            const float pxy = ssim_rowpass16(v[2][i], wj);
+            const float my = ssim_rowpass16(v[3][i], wj), sy = ssim_rowpass16(v[4][i], wj);
+            const float num0 = mx * my * 2.0f;
+            const float den0 = mx * mx + my * my;
+            const float N0 = num0 + SSIM_C1, D0 = den0 + SSIM_C1;
+            const float N1 = (pxy * 2.0f - num0) + SSIM_C2;
+            const float D1 = ((sx + sy) - den0) + SSIM_C2;
+            const float r0 = 1.0f / D0, r1 = 1.0f / D1;
+            const float lum = N0 * r0, cs = N1 * r1;
+            acc = fmaf(lum, cs, acc);
+            if (GRAD) {
+                const float dl = (2.0f * my - lum * (2.0f * mx)) * r0;
+                const float dc = (cs * (2.0f * mx) - 2.0f * my) * r1;
+                co[0][i] = -swc * fmaf(cs, dl, lum * dc);
+                co[1][i] = swc * ((lum * cs) * r1);
+                co[2][i] = -swc * ((lum + lum) * r1);
+            }
+        }
+        part -= swc * acc;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) co[q][i] = ssim_rowpass16(co[q][i], wj);
+            }
+            float g3[3][16];
+            ssim_colpass16<3>(co, g3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                xp[i * 16] = fmaf(in[3][i], g3[2][i], fmaf(in[0][i] + in[0][i], g3[1][i], g3[0][i]));
+        }
+    }
+    return part;
+}
+
+// ---------------------------------------------------------------------------
+// fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, bool HAS_LW, int HL>
+__device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
+                                                 const float* __restrict__ s_coords, const float* __restrict__ s_tgt,
+                                                 const float* __restrict__ s_lw, int N, int G, int sub,
+                                                 float* __restrict__ acc) {
+    const int pxl = (N + G - 1) / G;
+#pragma unroll 2
+    for (int i = 0; i < pxl; ++i) {
+        const int n = i * G + sub;
+        if (n < N) {
+            float x[D], t[C];
+#pragma unroll
+            for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+            const float lw = HAS_LW ? s_lw[n] : 1.0f;
+            PixelOut<D, C, K> o;
+            pixel<D, C, K, true, HL>(R, kc, x, t, lw, acc, o);
+        }
+    }
+}
+
+// HL = number of trailing axes whose index is the same for every pixel n = i*G + sub of a lane: the host
+// guarantees G % (block_shape[D-1] * ... * block_shape[D-HL]) == 0.  Terms in those coordinates are
+// hoisted out of the pixel loop (HL = 1 for 16x16 blocks with G = 16; HL = 2 for 16x16x4 with G = 64).
+// SSIM (ssim_opt, G == 64 and D == 2 only): loss_pixel = 1 - SSIM.  Per iteration: a forward-only sweep
+// leaves the quantised reconstruction of the block in LDS, the wavefront turns it into dL/dq
+// (ssim_block), and the usual fused sweep runs with that gradient instead of the margin loss.
+// QUANT: quantization_mode 2 / 3 (all variables fake-quantised in the graph).
+template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false>
+__global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
+    using Lt = Layout<D, C, K>;
+    using T = Tile<D, C, K, G, WAVES>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int B = a.B;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G;
+    const int sub = lane - grp * G;
+    const int blk0 = blockIdx.x * T::NB;
+    const int lb = wave * T::BPW + grp;
+    const int b_raw = blk0 + lb;
+    const bool valid_b = b_raw < B;
+    const int b = valid_b ? b_raw : B - 1;
+
+    constexpr int CR = D - HL;                     // only the coordinates read per pixel are staged
+    float* s_coords = lds + T::off_coords();
+    float* s_par = lds + T::off_par(N, CR) + lb * Lt::LP_STRIDE;
+    float* s_mv = lds + T::off_mv(N, CR) + lb * T::MV_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N, CR) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N, CR) + lb * (C * N);
+    const float* s_lw = lds + T::off_lw(N, CR) + lb * N;
+    const bool has_lw = a.loss_w != nullptr;
+
+    stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    // ssim_opt planes (see Tile::off_ssim)
+    float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
+    const int bh = a.bh, bw = a.bw;
+    const float* s_Tr = s_ssim;
+    const float* s_Tc = s_ssim + bh * 11;
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
+    float* s_Wa = s_X + C * N;
+    float* s_Wb = s_Wa + 5 * N;
+    float wj[11];                                  // G == 16: this lane's row-pass weights T16[sub][sub + a - 5]
+    if (SSIM) {
+        if (G == 16) {
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                wj[q] = a.ssim_T[11 * 16 + sub * 11 + q];
+            }
+        } else {
+            for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+        }
+    }
+    float xc[D];                                   // coordinates of the lane's pixel i = 0 (hoisted axes: all its pixels)
+#pragma unroll
+    for (int l = 0; l < D; ++l) xc[l] = a.coords[l * N + min(sub, N - 1)];
+
+    // ---- owner set-up: this lane owns packed slots sub, sub+G, ... of its block --------
+    // per-slot learning rate (0 = not trained) and l1 regulariser constant stay in registers;
+    // the parameter and its Adam slots live in LDS between iterations.
+    float lr[T::SPL], reg[T::SPL], qlo[T::SPL], qhi[T::SPL];
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        const int j = sub + s * G;
+        lr[s] = reg[s] = 0.0f;
+        qlo[s] = -__builtin_huge_valf(); qhi[s] = __builtin_huge_valf();
+        if (j < Lt::NPAR) {
+            int tensor, kern; long off;
+            decode_slot<D, C, K>(j, b, tensor, off, kern);
+            s_par[j] = pick(a.p, tensor)[off];
+            s_mv[2 * j] = pick(a.m, tensor)[off];
+            s_mv[2 * j + 1] = pick(a.v, tensor)[off];
+            // optimizer groups, smoe.py:1102-1104; untrainable variables dropped, 1112-1117
+            float r = (tensor == 0) ? a.lr_pis : ((tensor == 2 || tensor == 3) ? a.lr_steer : a.lr_expert);
+            if (tensor == 0 && !a.train_pis) r = 0.0f;
+            if (tensor == 1 && !a.train_musx) r = 0.0f;
+            if (tensor == 4 && !a.kc.train_gammas) r = 0.0f;
+            if (tensor == 4 && a.kc.only_y_gamma && (off % C) != 0) r = 0.0f;   // masked slopes get zero gradient
+            lr[s] = r;
+            reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? a.reg_u : 0.0f);   // smoe.py:1027,1044
+            // fixed-range fake quant of this variable: the gradient passes inside the nudged range only
+            const int qg = (tensor == 0) ? 3 : ((tensor == 1) ? 1 : ((tensor == 4) ? 4 : ((tensor == 5) ? 2 : 0)));
+            if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) { qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; }
+        } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+            const int k = j - Lt::S_CNT;
+            s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
+        } else if (j == Lt::S_LOSS) {
+            s_par[Lt::LP_FROZEN] = (a.diverged != nullptr && a.diverged[b] != 0u) ? 1.0f : 0.0f;
+        }
+    }
+    const float loss0 = (a.loss0 != nullptr) ? a.loss0[b] : 0.0f;
+    const bool has_loss0 = a.loss0 != nullptr;
+    const bool has_reg = (a.reg_pi != 0.0f) || (a.reg_u != 0.0f);
+    const bool has_quant = (a.kc.qmode != 0) || (a.kc.qpis != 0);
+    float last_loss = 0.0f, last_sse = 0.0f;
+    __syncthreads();
+
+    float b1p = a.b1p, b2p = a.b2p;
+    const KernelConsts kc = a.kc;
+    const float beta1 = a.beta1, beta2 = a.beta2, adam_eps = a.eps, clip = a.clip;
+    const float reg_pi = a.reg_pi, reg_u = a.reg_u;
+
+    for (int it = 0; it < a.n_iters; ++it) {
+        float acc[Lt::NSLOT];
+#pragma unroll
+        for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
+        bool frozen;
+        float reg_loss = 0.0f;
+        {
+            BlockRegs<D, C, K> R;
+            R.load(s_par);
+            if (has_quant) quantize_packed<D, C, K, QUANT>(R.P, kc);     // the graph sees the fake-quantised variables
+            R.derive(kc);
+            frozen = R.frozen();
+            if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (R.act(k)) {
+                        reg_loss += reg_pi * R.pi(k);
+#pragma unroll
+                        for (int l = 0; l < D; ++l) reg_loss += reg_u * R.A(k, l, l);
+                    }
+                }
+            }
+            if (HL > 0) hoist_const<D, C, K, HL>(R, xc);
+            if constexpr (SSIM) {
+                // the reference's SSIM branch does not use loss_weights (smoe.py:929-1010)
+                const int pxl = (N + G - 1) / G;
+                for (int i = 0; i < pxl; ++i) {                 // sweep 1: reconstruction only
+                    const int n = i * G + sub;
+                    if (n < N) {
+                        float x[D], t[C], scratch_acc[Lt::NSLOT];
+#pragma unroll
+                        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+#pragma unroll
+                        for (int j = 0; j < Lt::NSLOT; ++j) scratch_acc[j] = 0.0f;
+                        PixelOut<D, C, K> o;
+                        pixel<D, C, K, false, HL>(R, kc, x, t, 1.0f, scratch_acc, o);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+                    }
+                }
+                wave_lds_sync();
+                if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, true>(s_X, s_tgt, sub, wj, kc.sw);
+                else acc[Lt::S_LOSS] = ssim_block<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, kc.sw, bh, bw, N, lane);
+                for (int i = 0; i < pxl; ++i) {                 // sweep 2: forward again + backward with dL/dq
+                    const int n = i * G + sub;
+                    if (n < N) {
+                        float x[D], t[C], gq[C];
+#pragma unroll
+                        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) { t[c] = s_tgt[c * N + n]; gq[c] = s_X[c * N + n]; }
+                        PixelOut<D, C, K> o;
+                        pixel<D, C, K, true, HL, true>(R, kc, x, t, 1.0f, acc, o, gq);
+                    }
+                }
+            } else {
+                if (has_lw) pixel_loop_train<D, C, K, true, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+                else pixel_loop_train<D, C, K, false, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+            }
+            if (HL > 0) complete_const<D, C, K, HL>(xc, acc);
+        }
+        {
+            BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
+            R2.load(s_par);
+            if (has_quant) quantize_packed<D, C, K, QUANT>(R2.P, kc);
+            finish_partials<D, C, K>(R2, kc, acc);
+        }
+        if constexpr (QUANT) if (kc.qmode == 3) {            // back through fake_quant_with_min_max_vars
+            BlockRegs<D, C, K> R3;
+            R3.load(s_par);
+            route_quant_partials<D, C, K>(R3.P, kc, acc);
+        }
+
+        float total[T::SPL];
+        reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
+
+        // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
+        const float bias = sqrtf(1.0f - b2p) / (1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
+        float newp[T::SPL];
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            const int jc = (j < Lt::NPAR) ? j : 0;
+            const float pv = s_par[jc];
+            const float mv = s_mv[2 * jc];
+            const float vv = s_mv[2 * jc + 1];
+            float gsum = total[s];
+            if (has_reg && reg[s] != 0.0f) {
+                const int k = jc / Lt::PK;
+                float piv = s_par[k * Lt::PK + Lt::O_PI];
+                if (kc.qpis) piv = fq_val(piv, fq_fixed(kc, 3));
+                const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (piv > 0.0f);
+                gsum += act ? reg[s] : 0.0f;
+            }
+            gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;     // fixed-range fake quant: straight-through inside
+            if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
+            const float alpha = lr[s] * bias;
+            const float m2 = mv + (gsum - mv) * (1.0f - beta1);
+            const float v2 = vv + (gsum * gsum - vv) * (1.0f - beta2);
+            const float p2 = pv - (m2 * alpha) / (sqrtf(v2) + adam_eps);
+            const bool upd = (j < Lt::NPAR) && (lr[s] != 0.0f) && !frozen;
+            newp[s] = upd ? p2 : pv;
+            if (upd) { s_mv[2 * jc] = m2; s_mv[2 * jc + 1] = v2; }
+            if (j == Lt::S_LOSS && !frozen) {
+                const float lossv = (SSIM ? 1.0f + total[s] : total[s]) + reg_loss;     // smoe.py:1010: 1 - ssim
+                last_loss = lossv;
+                bad = (lossv != lossv) || (has_loss0 && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f));
+            }
+            if (j == Lt::S_SSE && !frozen) last_sse = total[s];
+        }
+        wave_lds_sync();   // every lane has consumed the old flags / params
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j < Lt::NPAR) {
+                s_par[j] = newp[s];
+            } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+                if (!frozen) s_par[Lt::LP_ACT + (j - Lt::S_CNT)] = (total[s] > 0.0f) ? 1.0f : 0.0f;
+            } else if (j == Lt::S_LOSS) {
+                if (bad) s_par[Lt::LP_FROZEN] = 1.0f;      // takes effect from the next iteration
+            }
+        }
+        wave_lds_sync();
+        b1p *= beta1;
+        b2p *= beta2;
+    }
+
+    // ---- write back (pointers are re-read from the kernarg segment: keeping 18 of them
+    // live across the iteration loop costs SGPR spills inside it) ------------------------
+    const FitArgs* ka = (const FitArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    if (valid_b) {
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j < Lt::NPAR) {
+                int tensor, kern; long off;
+                decode_slot<D, C, K>(j, b, tensor, off, kern);
+                pick(ka->p, tensor)[off] = s_par[j];
+                pick(ka->m, tensor)[off] = s_mv[2 * j];
+                pick(ka->v, tensor)[off] = s_mv[2 * j + 1];
+            } else if (j == Lt::S_LOSS) {
+                if (ka->loss_out != nullptr && ka->n_iters > 0) ka->loss_out[b] = last_loss;
+                if (ka->diverged != nullptr) ka->diverged[b] = (s_par[Lt::LP_FROZEN] != 0.0f) ? 1u : 0u;
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int k = 0; k < K; ++k) mask |= (s_par[Lt::LP_ACT + k] != 0.0f) ? (1u << k) : 0u;
+                ka->active[b] = mask;
+            } else if (j == Lt::S_SSE) {
+                if (ka->sse_out != nullptr && ka->n_iters > 0) ka->sse_out[b] = last_sse;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward (evaluation) kernel
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false>
+__global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
+    using Lt = Layout<D, C, K>;
+    using T = Tile<D, C, K, G, WAVES>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int N = a.N;
+    const int B = a.B;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G;
+    const int sub = lane - grp * G;
+    const int blk0 = blockIdx.x * T::NB;
+    const int lb = wave * T::BPW + grp;
+    const int b_raw = blk0 + lb;
+    const bool valid_b = b_raw < B;
+    const int b = valid_b ? b_raw : B - 1;
+
+    float* s_coords = lds + T::off_coords();
+    float* s_par = lds + T::off_par(N, D) + lb * Lt::LP_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N, D) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N, D) + lb * (C * N);
+    const float* s_lw = lds + T::off_lw(N, D) + lb * N;
+    const bool has_lw = a.loss_w != nullptr;
+
+    stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    float* s_ssim = lds + T::off_ssim(N, has_lw, D);
+    const int bh = a.bh, bw = a.bw;
+    const float* s_Tr = s_ssim;
+    const float* s_Tc = s_ssim + bh * 11;
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
+    float* s_Wa = s_X + C * N;
+    float* s_Wb = s_Wa + 5 * N;
+    float wj[11];
+    if (SSIM) {
+        if (G == 16) {
+#pragma unroll
+            for (int q = 0; q < 11; ++q) {
+                wj[q] = a.ssim_T[11 * 16 + sub * 11 + q];
+            }
+        } else {
+            for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        const int j = sub + s * G;
+        if (j < Lt::NPAR) {
+            int tensor, kern; long off;
+            decode_slot<D, C, K>(j, b, tensor, off, kern);
+            s_par[j] = pick(a.p, tensor)[off];
+        } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+            const int k = j - Lt::S_CNT;
+            s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
+        } else if (j == Lt::S_LOSS) {
+            s_par[Lt::LP_FROZEN] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    BlockRegs<D, C, K> R;
+    R.load(s_par);
+    if (a.kc.qmode != 0 || a.kc.qpis != 0) quantize_packed<D, C, K, QUANT>(R.P, a.kc);
+    R.derive(a.kc);
+
+    float acc[Lt::NSLOT];
+#pragma unroll
+    for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
+
+    const int pxl = (N + G - 1) / G;
+    for (int i = 0; i < pxl; ++i) {
+        const int n = i * G + sub;
+        if (n < N) {
+            float x[D], t[C];
+#pragma unroll
+            for (int l = 0; l < D; ++l) x[l] = s_coords[l * N + n];
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+            const float lw = has_lw ? s_lw[n] : 1.0f;
+            PixelOut<D, C, K> o;
+            pixel<D, C, K, false>(R, a.kc, x, t, lw, acc, o);
+            if (SSIM) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+            }
+            if (valid_b) {
+                if (a.recon != nullptr) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) a.recon[((size_t)b * C + c) * N + n] = o.q[c];
+                }
+                if (a.gate_w != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) a.gate_w[((size_t)b * K + k) * N + n] = o.wt[k];
+                }
+                if (a.argmax != nullptr) {
+                    // tf.argmax over the kernels with influence (smoe.py:833): first maximum;
+                    // a pixel with no influential kernel resolves to the first listed kernel
+                    // of the block, which is only known after the block reduction -> 255 for now.
+                    float best = 0.0f;
+                    int arg = 255;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (o.wt[k] > best) { best = o.wt[k]; arg = k; }
+                    }
+                    a.argmax[(size_t)b * N + n] = (uint8_t)arg;
+                }
+            }
+        }
+    }
+
+    if constexpr (SSIM) {                              // loss_pixel = 1 - SSIM (smoe.py:1006-1010)
+        wave_lds_sync();
+        if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, false>(s_X, const_cast<float*>(s_tgt), sub, wj, a.kc.sw);
+        else acc[Lt::S_LOSS] = ssim_block<C, false>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, N, lane);
+    }
+    float total[T::SPL];
+    reduce_slots<D, C, K, G, WAVES, Layout<D, C, K>::NPAR>(acc, s_scratch, lane, total);
+
+    // publish the influence flags of the block through LDS (needed by every lane below)
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        const int j = sub + s * G;
+        if (j >= Lt::S_CNT && j < Lt::S_CNT + K) s_scratch[j - Lt::S_CNT + grp * 16] = (total[s] > 0.0f) ? 1.0f : 0.0f;
+    }
+    wave_lds_sync();
+    uint32_t newmask = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) newmask |= (s_scratch[k + grp * 16] != 0.0f) ? (1u << k) : 0u;
+
+    if (valid_b) {
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j == Lt::S_LOSS) {
+                float lossv = SSIM ? 1.0f + total[s] : total[s];
+                if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const bool act = R.act(k);
+                        if (act) {
+                            lossv += a.reg_pi * R.pi(k);
+#pragma unroll
+                            for (int l = 0; l < D; ++l) lossv += a.reg_u * R.A(k, l, l);
+                        }
+                    }
+                }
+                if (a.loss != nullptr) a.loss[b] = lossv;
+                if (a.update_active) a.active[b] = newmask;
+            } else if (j == Lt::S_SSE) {
+                if (a.sse != nullptr) a.sse[b] = total[s];
+            }
+        }
+        if (a.argmax != nullptr) {
+            const int first = (newmask != 0u) ? (__ffs(newmask) - 1) : 0;
+            for (int i = 0; i < pxl; ++i) {
+                const int n = i * G + sub;
+                if (n < N) {
+                    uint8_t* p8 = a.argmax + (size_t)b * N + n;
+                    if (*p8 == 255) *p8 = (uint8_t)first;
+                }
+            }
+        }
+    }
+}
+
+// update_kernel_list when the graph is built on fake-quantised variables: the probe test (smoe.py:806) sees
+// q(A), q(musX) and pis_mask = qpis > 0.  One thread per block (mode-3 ranges need all its kernels).
+template <int D, int C, int K>
+__global__ void readmit_quant_kernel(ReadmitArgs a, KernelConsts kc) {
+    using Lt = Layout<D, C, K>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    float P[Lt::NPAR];
+#pragma unroll
+    for (int j = 0; j < Lt::NPAR; ++j) {
+        int tensor, kern; long off;
+        decode_slot<D, C, K>(j, b, tensor, off, kern);
+        P[j] = pick(a.p, tensor)[off];
+    }
+    quantize_packed<D, C, K, true>(P, kc);
+    int nprobe = 1;
+#pragma unroll
+    for (int l = 0; l < D; ++l) nprobe *= 3;
+    uint32_t add = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float* p = P + k * Lt::PK;
+        bool near = false;
+        for (int q = 0; q < nprobe; ++q) {
+            float r[D];
+            int rem = q;
+#pragma unroll
+            for (int l = D - 1; l >= 0; --l) {
+                const int sel = rem % 3;
+                rem /= 3;
+                r[l] = a.probes[l * 3 + sel] - p[Lt::O_MU + l];
+            }
+            float maha = 0.0f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float zz = 0.0f;
+#pragma unroll
+                for (int l = m; l < D; ++l) zz = fmaf(r[l], p[Lt::O_A + tri_index(l, m)], zz);
+                maha = fmaf(zz, zz, maha);
+            }
+            near = near || (maha < 800.0f);
+        }
+        if (near && p[Lt::O_PI] > 0.0f) add |= 1u << k;
+    }
+    a.active[b] |= add;
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_readmit_quant(const ReadmitArgs& a, const KernelConsts& kc, hipStream_t st) {
+    const int threads = 64;
+    hipLaunchKernelGGL((readmit_quant_kernel<D, C, K>), dim3((a.B + threads - 1) / threads), dim3(threads), 0, st, a, kc);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// launchers + dispatch table
+// ---------------------------------------------------------------------------
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 0>;
+    int hl = 0;
+    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
+    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
+    auto kern = forward_kernel<D, C, K, G, WAVES>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+// quantization_mode 2 / 3 launches
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 0, false, true>;
+    int hl = 0;
+    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, true>; hl = 1; }
+    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
+    auto kern = forward_kernel<D, C, K, G, WAVES, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+// ssim_opt launches: instantiated for 2-d blocks on the one-block-per-wavefront tiling only
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
+    if constexpr (D == 2) {
+        using T = Tile<D, C, K, G, WAVES>;
+        if (G == 16 && (a.bh != 16 || a.bw != 16 || hoist < 1)) return hipErrorNotSupported;   // register path: 16x16 only
+        auto kern = fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
+        int hl = (G == 16) ? 1 : 0;
+        if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        const int grid = (a.B + T::NB - 1) / T::NB;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
+    if constexpr (D == 2) {
+        using T = Tile<D, C, K, G, WAVES>;
+        if (G == 16 && (a.bh != 16 || a.bw != 16)) return hipErrorNotSupported;
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw);
+        auto kern = forward_kernel<D, C, K, G, WAVES, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        const int grid = (a.B + T::NB - 1) / T::NB;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorNotSupported;
+    }
+}
+
+template <int D, int C, int K, int G, int WAVES>
+size_t lds_bytes(int N, bool has_lw) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw); }
+
+template <int D, int C, int K, int G, int WAVES>
+size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw) {
+    if (D != 2 || (G == 16 && (bh != 16 || bw != 16))) return (size_t)-1;
+    return Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw);
+}
+
+template <int D, int C, int K, int G, int WAVES>
+int fit_occupancy(int N, bool has_lw) {
+    using T = Tile<D, C, K, G, WAVES>;
+    int nb = 0;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 1>;
+    const size_t shm = T::bytes(N, has_lw, D - 1);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, shm) != hipSuccess) return -1;
+    return nb * WAVES;       // resident wavefronts per CU
+}
+
+#define SMOE_VARIANT(D, C, K, G, W) \
+    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
+      &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W>, \
+      &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W> }
+
+}  // namespace smoe
+#endif
