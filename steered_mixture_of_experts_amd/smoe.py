@@ -577,7 +577,7 @@ class SharedSmoe:
                  batch_size=None, train_gammas=True, train_musx=True, use_determinant=False, normalize_pis=True,
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
                  engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
-                 upper_bounds=None, **unsupported):
+                 upper_bounds=None, only_y_gamma=False, use_diff_center=False, **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
@@ -599,7 +599,11 @@ class SharedSmoe:
         self.bit_depths = [20, 18, 6, 10, 10] if bit_depths is None else list(bit_depths)
         self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
         self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
-        self.only_y_gamma = self.ssim_opt = self.use_diff_center = self.radial_as = False
+        self.ssim_opt = self.radial_as = False
+        self.only_y_gamma = bool(only_y_gamma) and self.use_yuv          # smoe_test.py:43-44, smoe.py:725-729
+        self.use_diff_center = bool(use_diff_center)
+        if quantization_mode >= 2 and use_diff_center:
+            raise NotImplementedError("fake-quantised centre OFFSETS are not built: the engine works on absolute centres")
         self.overlap = int(overlap_of_batches)                            # smoe.py:244
         if batch_size is None or batch_size[0] is None:
             bs = blk.get_batch_shape(start_batches, tuple(image.shape[:d]) + (d + image.shape[-1],))[:-1]
@@ -629,6 +633,9 @@ class SharedSmoe:
             p0 = {k: v[0] for k, v in blk.init_block_params(image[None], kpd, normalize_pis).items()}
             self.musX_init = blk.gen_domain_grid(kpd, d)
         self.kernels = self.start_pis = self.kernel_count = p0["pis"].shape[0]
+        # use_diff_center (smoe.py:390-394,746-747): the trained variable is the offset from the kernel grid; the
+        # engine works on grid + offset, the getters subtract the grid
+        self._mus_grid = np.ascontiguousarray(p0["musX"]).copy() if self.use_diff_center else None
         self._factory = engine_factory or _default_shared_factory
         self._device = device
         self._engine, self._engine_key = None, None
@@ -661,7 +668,7 @@ class SharedSmoe:
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
             start_pis=self.kernels, overlap=self.overlap, quantization_mode=self.quantization_mode,
             quantize_pis=self.quantize_pis, bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
-            upper_bounds=tuple(self.upper_bounds))
+            upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma)
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:
@@ -787,11 +794,17 @@ class SharedSmoe:
             print("end loss/mse: ", loss_val, "/", mse_val, "@iter: ", i)
             print("best loss/mse: ", self.best_loss, "/", self.best_mse)
 
+    def _host_params(self, p):
+        out = {k: v.cpu().numpy().copy() for k, v in p.items()}
+        if self._mus_grid is not None:                     # use_diff_center: report the trained offsets
+            out["musX"] = out["musX"] - self._mus_grid
+        return out
+
     def get_params(self):
-        return {k: v.cpu().numpy().copy() for k, v in self._params.items()}
+        return self._host_params(self._params)
 
     def get_best_params(self):
-        return {k: v.cpu().numpy().copy() for k, v in self._best.items()}
+        return self._host_params(self._best)
 
     def get_reconstruction(self):
         if not self.valid:

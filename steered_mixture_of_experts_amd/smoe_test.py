@@ -125,9 +125,10 @@ def main(args):
                     lower_bounds=args.lower_bounds, upper_bounds=args.upper_bounds, only_y_gamma=only_y_gamma,
                     loss_mask=loss_mask, ssim_opt=args.ssim_opt, **common)
     else:
-        if args.use_diff_center or only_y_gamma or loss_mask is not None or args.ssim_opt:
-            raise NotImplementedError("--mode shared: use_diff_center / only_y_gamma / loss masks / SSIM are not built")
-        smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, quantization_mode=args.quantization_mode,
+        if loss_mask is not None or args.ssim_opt:
+            raise NotImplementedError("--mode shared: loss masks / SSIM are not built")
+        smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, only_y_gamma=only_y_gamma,
+                          use_diff_center=args.use_diff_center, quantization_mode=args.quantization_mode,
                           quantize_pis=args.quantize_pis, bit_depths=args.bit_depths, lower_bounds=args.lower_bounds,
                           upper_bounds=args.upper_bounds, **common)
     optimizer1 = Adam(args.base_lr)                                                   # smoe_test.py:84-86

@@ -386,3 +386,24 @@ def test_shared_facade_with_fake_quantised_variables(mode):
         with pytest.raises(NotImplementedError):
             SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], engine_factory=OracleSharedEngine,
                        quantization_mode=bad)
+
+
+def test_shared_facade_only_y_gamma_and_diff_center():
+    """only_y_gamma (gamma_mask, smoe.py:725-729) and use_diff_center (smoe.py:390-394,746-747) in the shared mode."""
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(32, 32, C=3, seed=2)
+    s = SharedSmoe(img, kernels_per_dim=[3, 3], batch_size=[16, 16], use_determinant=True, use_yuv=True,
+                   only_y_gamma=True, use_diff_center=True, engine_factory=OracleSharedEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    assert np.array_equal(s.get_params()["musX"], np.zeros((9, 2), np.float32))      # offsets start at zero
+    s.train(4, val_iter=2)
+    p = s.get_params()
+    assert np.abs(p["musX"]).max() < 0.02 and np.abs(p["musX"]).max() > 0
+    assert not p["gamma_e"][..., 1:].any() and p["gamma_e"][..., 0].any()
+    p0 = o.shared_init_params(img, [3, 3])
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=3, kernels=9, lr_steer=0.01, use_yuv=True, only_y_gamma=True)
+    pn, _, _ = o.shared_fit(p0, tb.reshape(4, -1, 3), o.global_batch_coords((32, 32), (16, 16)), cfg, 4, val_iter=2)
+    assert np.allclose(p["musX"] + p0["musX"][0], pn["musX"][0], atol=2e-6)
+    assert np.allclose(p["nu_e"], pn["nu_e"][0], atol=2e-6)
