@@ -70,6 +70,8 @@ class OracleConfig:
     only_y_gamma: bool = False            # smoe.py:725-729 (slopes only for channel 0)
     ssim_opt: bool = False                # smoe.py:929,980-1011: loss_pixel = 1 - SSIM (2-d blocks)
     # fake-quantised parameters inside the graph (smoe.py:474-538); order of the 5-tuples: A, musX, nu_e, pis, gamma_e
+    train_inverse_cov: bool = False       # smoe.py:734-735,791-793: A symmetric, maha = r^T A r (the ctor default is
+                                          # True, the CLI default False, smoe_test.py:342)
     quantization_mode: int = 0            # 0/1: none in the graph; 2: fixed ranges; 3: min/max of the model's kernels
     quantize_pis: bool = False            # smoe.py:474 (the reference CLI passes True by default, smoe_test.py:304)
     bit_depths: Tuple[int, ...] = (20, 18, 6, 10, 10)                 # smoe_test.py:302
@@ -176,14 +178,26 @@ def new_adam_state(p: Dict[str, np.ndarray]) -> Dict[str, object]:
 # --------------------------------------------------------------------------
 # forward
 # --------------------------------------------------------------------------
-def _steering(p, T):
-    """A = diag(A_diagonal) + strict_lower(A_corr), smoe.py:732-733."""
+def _steering(p, T, symmetric=False):
+    """A = diag(A_diagonal) + strict_lower(A_corr), smoe.py:732-733; train_inverse_cov adds the transposed
+    strict lower part (smoe.py:734-735)."""
     Ad = p["A_diagonal"].astype(T)
     Ac = p["A_corr"].astype(T)
     d = Ad.shape[-1]
     eye = np.eye(d, dtype=bool)
     low = np.tril(np.ones((d, d), dtype=bool), -1)
-    return np.where(eye, Ad, 0) + np.where(low, Ac, 0)
+    A = np.where(eye, Ad, 0) + np.where(low, Ac, 0)
+    if symmetric:
+        A = A + np.swapaxes(np.where(low, Ac, 0), -1, -2)
+    return A
+
+
+def _maha(r, A, inverse_cov):
+    """smoe.py:791-796: r^T A r for train_inverse_cov, |A^T r|^2 otherwise.  Returns (maha, z) with z = A^T r."""
+    z = np.einsum("...nl,...lm->...nm", r, A)                # z_m = sum_l r_l A[l,m]
+    if inverse_cov:
+        return np.sum(z * r, axis=-1), z
+    return np.sum(z * z, axis=-1), z
 
 
 def fake_quant01(y, precision, T):
@@ -416,7 +430,8 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     if y_only:
         gam = gam.copy()
         gam[..., 1:] = T(0)                                  # qgamma_e * gamma_mask
-    A = _steering(p, T)                                      # (B,K,d,d)
+    ic = cfg.train_inverse_cov
+    A = _steering(p, T, ic)                                  # (B,K,d,d)
     lw = np.ones((B, N), dtype=T) if loss_w is None else loss_w.astype(T)
 
     # smoe.py:480,738: bool_mask = kernel_list & (pis > 0)
@@ -424,8 +439,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
 
     # smoe.py:777-782,796: r = x - mu ; z = A^T r ; maha = |z|^2
     r = x[:, None, :, :] - mu[:, :, None, :]                 # (B,K,N,d)
-    z = np.einsum("bknl,bklm->bknm", r, A)                   # z_m = sum_l r_l A[l,m]
-    maha = np.sum(z * z, axis=-1)                            # (B,K,N)
+    maha, z = _maha(r, A, ic)                                # (B,K,N)
     n_exp = np.exp(T(-0.5) * maha)                           # smoe.py:807
     if cfg.use_determinant:                                  # smoe.py:809-815
         n_div = np.prod(np.diagonal(A, axis1=-2, axis2=-1), axis=-1)   # (B,K)
@@ -503,7 +517,11 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     safe_pi = np.where(act, pis, T(1))
     g_pi = np.where(act, np.sum(u, axis=2) / safe_pi + T(cfg.pis_l1) / T(cfg.k0), T(0))
     # steering: dm/dA[l,m] = 2 r_l z_m, dL/dm = -u/2
-    g_A = -np.einsum("bkn,bknl,bknm->bklm", u, r, z)         # (B,K,d,d), valid for l>=m
+    if ic:      # maha = r^T A r: dm/dA_ll = r_l^2, dm/dA_corr[l,m] = 2 r_l r_m (the entry sits at (l,m) and (m,l))
+        rr = np.einsum("bkn,bknl,bknm->bklm", u, r, r)
+        g_A = -T(0.5) * rr * np.where(np.eye(d, dtype=bool), T(1), T(2))
+    else:       # dm/dA[l,m] = 2 r_l z_m
+        g_A = -np.einsum("bkn,bknl,bknm->bklm", u, r, z)     # (B,K,d,d), valid for l>=m
     if cfg.use_determinant:
         safe_d = np.where(act[:, :, None], diagA, T(1))
         g_A = g_A + np.einsum("bk,bkl,lm->bklm", np.sum(u, axis=2), T(1) / safe_d,
@@ -514,7 +532,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     g_Adiag = np.where(eye, g_A, T(0))
     g_Acorr = np.where(low, g_A, T(0))
     # centres: dm/dmu = -2 A z
-    Az = np.einsum("bklm,bknm->bknl", A, z)
+    Az = z if ic else np.einsum("bklm,bknm->bknl", A, z)    # dm/dmu = -2 A r (symmetric A) resp. -2 A A^T r
     g_mu = np.einsum("bkn,bknl->bkl", u, Az)
     if not cfg.train_gammas:
         g_gam = np.zeros_like(g_gam)
@@ -588,11 +606,10 @@ def readmit(p, active, cfg: OracleConfig, dtype=np.float32):
     probes = np.array(list(itertools.product(*tt))).astype(np.float32).astype(T)   # (3^d, d)
     if cfg.quantization_mode >= 2 or cfg.quantize_pis:      # maha_dist_ind is part of the same graph (smoe.py:806)
         p = quantize_graph_params(p, cfg, T)[0]
-    A = _steering(p, T)
+    A = _steering(p, T, cfg.train_inverse_cov)
     mu = p["musX"].astype(T)
     r = probes[None, None, :, :] - mu[:, :, None, :]
-    z = np.einsum("bknl,bklm->bknm", r, A)
-    maha = np.sum(z * z, axis=-1)
+    maha, _ = _maha(r, A, cfg.train_inverse_cov)
     near = np.any(maha < T(800), axis=2)
     return np.logical_or(active, np.logical_and(near, p["pis"] > 0))
 
@@ -733,14 +750,13 @@ def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):   # c
     tt = np.stack([mins, maxs, (mins + maxs) / 2], axis=-1)                       # (NB,d,3)
     if cfg.quantization_mode >= 2 or cfg.quantize_pis:      # the probe test is part of the fake-quantised graph
         p = quantize_graph_params(p, cfg, T)[0]
-    A = _steering(p, T)[0]
+    A = _steering(p, T, cfg.train_inverse_cov)[0]
     mu = p["musX"].astype(T)[0]
     out = lists.copy()
     for b in range(NB):
         probes = np.array(list(itertools.product(*tt[b]))).astype(np.float32).astype(T)
         r = probes[None, :, :] - mu[:, None, :]
-        z = np.einsum("knl,klm->knm", r, A)
-        near = np.any(np.sum(z * z, axis=-1) < T(800), axis=1)
+        near = np.any(_maha(r, A, cfg.train_inverse_cov)[0] < T(800), axis=1)
         out[b] |= near & (p["pis"][0] > 0)
     return out
 

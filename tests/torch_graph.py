@@ -140,7 +140,8 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
                    use_determinant=True, use_yuv=False, train_gammas=True,
                    pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None,
                    quantization_mode=0, quantize_pis=False, bit_depths=(20, 18, 6, 10, 10),
-                   lower_bounds=(-2500, -.3, -5, 0, -32), upper_bounds=(2500, 1.3, 5, 2, 32), train_musx=True):
+                   lower_bounds=(-2500, -.3, -5, 0, -32), upper_bounds=(2500, 1.3, 5, 2, 32), train_musx=True,
+                   train_inverse_cov=False):
     """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
     with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
     Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
@@ -156,13 +157,18 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
     dt = coords.dtype
     # smoe.py:732-733  band_part(A_diagonal,0,0) + band_part(set_diag(A_corr,0),-1,0)
     A = torch.diag_embed(torch.diagonal(Ad_v, dim1=-2, dim2=-1)) + torch.tril(Ac_v, diagonal=-1)
+    if train_inverse_cov:                                                        # smoe.py:734-735
+        A = A + torch.tril(Ac_v, diagonal=-1).transpose(-1, -2)
     # smoe.py:480,738-753
     bool_mask = kernel_list & pis_mask
     indices = torch.arange(K)[bool_mask]
     musX, nu_e, gamma_e, A, pis = musX_v[bool_mask], nu_v[bool_mask], gam_v[bool_mask], A[bool_mask], pis_v[bool_mask]
     # smoe.py:777-782,796
     x_sub_mu = (coords.unsqueeze(0) - musX.unsqueeze(1)).unsqueeze(-1)          # (K,N,d,1)
-    maha = torch.einsum("abli,alm,anm,abnj->ab", x_sub_mu, A, A, x_sub_mu)
+    if train_inverse_cov:                                                        # smoe.py:791-793
+        maha = torch.einsum("abli,alm,abmj->ab", x_sub_mu, A, x_sub_mu)
+    else:
+        maha = torch.einsum("abli,alm,anm,abnj->ab", x_sub_mu, A, A, x_sub_mu)
     n_exp = torch.exp(-0.5 * maha)                                               # smoe.py:807
     if use_determinant:                                                          # smoe.py:809-815
         n_div = torch.prod(torch.diagonal(A, dim1=-2, dim2=-1), dim=-1)
