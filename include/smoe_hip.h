@@ -84,6 +84,9 @@ typedef struct smoe_config {
     int32_t bit_depths[5];
     float   lower_bounds[5];
     float   upper_bounds[5];
+    int32_t train_inverse_cov;  /* A symmetric (diag + A_corr + A_corr^T), maha = r^T A r; the determinant factor keeps
+                                   prod(diag A).  Reference CONSTRUCTOR default True, CLI default False
+                                   (smoe.py:41,734-735,791-793; smoe_test.py:342)                               */
 } smoe_config;
 
 /* Parameter set in the reference's get_params() layout (smoe.py:1795-1800) with a

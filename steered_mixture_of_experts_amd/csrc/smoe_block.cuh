@@ -123,6 +123,7 @@ struct BlockRegs {
     // hoisting (HL = number of trailing coordinates that are the same for all pixels of the lane):
     float hz[K][D];           // sum_{l>=D-HL} x_l A'[l][m] - c[m]   (z' = sum_{l<D-HL} x_l A'[l][m] + hz[m])
     float he[K][C];           // nu + sum_{l>=D-HL} gamma[l] x_l      (e  = he + sum_{l<D-HL} gamma[l] x_l)
+    float hq[K];              // train_inverse_cov: the part of r^T A' r made of hoisted coordinates only
 
     __device__ __forceinline__ float pi(int k) const { return P[k * Lt::PK + Lt::O_PI]; }
     __device__ __forceinline__ float mu(int k, int l) const { return P[k * Lt::PK + Lt::O_MU + l]; }
@@ -143,6 +144,10 @@ struct BlockRegs {
     }
 
     // smoe.py:480,738 (bool_mask = kernel_list & pis>0), 809-819 (determinant factor, * pis)
+    // IC (train_inverse_cov, smoe.py:734-735,791-793): A is symmetric and maha = r^T A r, so
+    // exp(-maha/2) = exp2(-r^T A' r) with A' = SQ^2 A; As holds the coefficients c_lm of the quadratic
+    // form over l >= m (c_ll = A'_ll, c_lm = 2 A'_lm).
+    template <bool IC = false>
     __device__ __forceinline__ void derive(const KernelConsts& kc) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -154,12 +159,15 @@ struct BlockRegs {
 #pragma unroll
             for (int l = 0; l < D; ++l)
 #pragma unroll
-                for (int m = 0; m <= l; ++m) As[k][tri_index(l, m)] = SMOE_SQ * A(k, l, m);
+                for (int m = 0; m <= l; ++m)
+                    As[k][tri_index(l, m)] = (IC ? ((l == m) ? SMOE_SQ * SMOE_SQ : 2.0f * SMOE_SQ * SMOE_SQ) : SMOE_SQ) * A(k, l, m);
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 float c = 0.0f;
+                if (!IC) {
 #pragma unroll
-                for (int l = m; l < D; ++l) c = fmaf(mu(k, l), As[k][tri_index(l, m)], c);
+                    for (int l = m; l < D; ++l) c = fmaf(mu(k, l), As[k][tri_index(l, m)], c);
+                }
                 cz[k][m] = c;
             }
             if (!kc.train_gammas) {          // smoe.py:841-848: the slopes are not part of the graph
@@ -382,10 +390,29 @@ __device__ __forceinline__ void route_quant_partials(const float* Praw, const Ke
 // (Measured dead end, kept as a note: with G == 64 the block's derived constants are wave-uniform and could live in
 // SGPRs, but VALU forms with an SGPR source issue at ~4.8 vs ~3.2 cycles and the readfirstlanes add ~100 instructions
 // per iteration: 32x32 / K=8 / C=3 went 63 -> 49 Gpx-it/s.)
-template <int D, int C, int K, int HL>
+template <int D, int C, int K, int HL, bool IC = false>
 __device__ __forceinline__ void hoist_const(BlockRegs<D, C, K>& R, const float (&xc)[D]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+        if (IC) {
+            // r_l = x_l - mu_l is a lane constant for l >= D-HL: hz[m] (m < D-HL) = sum_l c_lm r_l, hq = the terms
+            // with both indices hoisted;  maha' = hq + sum_{m < D-HL} (c_mm r_m + sum_{m' < m} c_mm' r_m' + hz[m]) r_m
+            float rh[D];
+#pragma unroll
+            for (int l = 0; l < D; ++l) rh[l] = (l >= D - HL) ? xc[l] - R.mu(k, l) : 0.0f;
+            float q = 0.0f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                float h = 0.0f;
+#pragma unroll
+                for (int l = D - HL; l < D; ++l) {
+                    if (l > m && m < D - HL) h = fmaf(R.As[k][tri_index(l, m)], rh[l], h);
+                    if (l >= m && m >= D - HL) q = fmaf(R.As[k][tri_index(l, m)] * rh[l], rh[m], q);
+                }
+                R.hz[k][m] = h;
+            }
+            R.hq[k] = q;
+        } else {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             float h = -R.cz[k][m];
@@ -393,6 +420,7 @@ __device__ __forceinline__ void hoist_const(BlockRegs<D, C, K>& R, const float (
             for (int l = D - 1; l >= D - HL; --l)
                 if (l >= m) h = fmaf(xc[l], R.As[k][tri_index(l, m)], h);
             R.hz[k][m] = h;
+        }
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -420,7 +448,7 @@ struct PixelOut {
 // EXTG (ssim_opt): dL/dq of the pixel comes from the caller (gext[c], the SSIM adjoint) instead of the
 // margin loss; the clip / fake-quant straight-through mask is still applied here and the loss slot is
 // left to the caller.
-template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false>
+template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false, bool IC = false>
 __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                       const float (&x)[D], const float (&t)[C], float lw,
                                       float* __restrict__ acc, PixelOut<D, C, K>& o,
@@ -432,6 +460,21 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float maha = 0.0f;
+        if (IC) {
+            // smoe.py:791-793: maha = r^T A r, evaluated on the non-hoisted coordinates (see hoist_const);
+            // z[k][l] keeps r_l for the reverse pass
+            maha = (HL > 0) ? R.hq[k] : 0.0f;
+#pragma unroll
+            for (int l = 0; l < D - HL; ++l) {
+                z[k][l] = x[l] - R.mu(k, l);
+                float tq = (HL > 0) ? R.hz[k][l] : 0.0f;
+#pragma unroll
+                for (int m = 0; m <= l; ++m) tq = fmaf(R.As[k][tri_index(l, m)], z[k][m], tq);
+                maha = fmaf(tq, z[k][l], maha);
+            }
+#pragma unroll
+            for (int l = D - HL; l < D; ++l) z[k][l] = 0.0f;
+        } else {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             float zz = (HL > 0) ? R.hz[k][m] : -R.cz[k][m];
@@ -439,6 +482,7 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
             for (int l = D - 1 - HL; l >= m; --l) zz = fmaf(x[l], R.As[k][tri_index(l, m)], zz);
             z[k][m] = zz;
             maha = (m == 0) ? zz * zz : fmaf(zz, zz, maha);
+        }
         }
         g[k] = R.coef[k] * fast_exp2(-maha);
         S = (k == 0) ? g[k] : S + g[k];
@@ -496,6 +540,16 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         const float u = fmaf(o.wt[k], eg, -(w[k] * dot));
         float* a = acc + k * Lt::PK;
         a[Lt::O_PI] += u;
+        if (IC) {
+            // raw sums of u r_l and u r_l r_m over the non-hoisted coordinates (the rest follows from them, complete_const)
+#pragma unroll
+            for (int l = 0; l < D - HL; ++l) {
+                const float ur = u * z[k][l];
+                a[Lt::O_MU + l] += ur;
+#pragma unroll
+                for (int m = 0; m <= l; ++m) a[Lt::O_A + tri_index(l, m)] = fmaf(ur, z[k][m], a[Lt::O_A + tri_index(l, m)]);
+            }
+        } else {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             const float uz = u * z[k][m];
@@ -503,6 +557,7 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
 #pragma unroll
             for (int l = m; l < D - HL; ++l)               // hoisted rows l >= D-HL are x_l * sum(uz), done after the loop
                 a[Lt::O_A + tri_index(l, m)] = fmaf(x[l], uz, a[Lt::O_A + tri_index(l, m)]);
+        }
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -516,16 +571,24 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
 }
 
 // Hoisting: complete the accumulators whose x factor is one of the lane-constant coordinates.
-template <int D, int C, int K, int HL>
-__device__ __forceinline__ void complete_const(const float (&xc)[D], float* __restrict__ acc) {
+template <int D, int C, int K, int HL, bool IC = false>
+__device__ __forceinline__ void complete_const(const BlockRegs<D, C, K>& R, const float (&xc)[D], float* __restrict__ acc) {
     using Lt = Layout<D, C, K>;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float* a = acc + k * Lt::PK;
 #pragma unroll
         for (int l = D - HL; l < D; ++l) {
+            if (IC) {       // sum u r_l = r_l sum u ; sum u r_l r_m = r_l sum u r_m (m not hoisted) = r_l r_m sum u (m hoisted)
+                const float rl = xc[l] - R.mu(k, l);
+#pragma unroll
+                for (int m = 0; m <= l; ++m)
+                    a[Lt::O_A + tri_index(l, m)] = (m < D - HL) ? rl * a[Lt::O_MU + m] : rl * ((xc[m] - R.mu(k, m)) * a[Lt::O_PI]);
+                a[Lt::O_MU + l] = rl * a[Lt::O_PI];
+            } else {
 #pragma unroll
             for (int m = 0; m <= l; ++m) a[Lt::O_A + tri_index(l, m)] = xc[l] * a[Lt::O_MU + m];
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) a[Lt::O_GA + l * C + c] = xc[l] * a[Lt::O_NU + c];
         }
@@ -538,7 +601,9 @@ __device__ __forceinline__ void complete_const(const float (&xc)[D], float* __re
 //   d/dpi   = (sum u) / pi
 //   d/dmu_l = sum_m A[l][m] suz_m                        (dm/dmu = -2 A z, dL/dm = -u/2)
 //   d/dA_lm = -(sxz_lm - mu_l suz_m) + [l==m, use_det] (sum u)/A_ll
-template <int D, int C, int K>
+//   train_inverse_cov (IC), raw sums sur_l = sum u r_l, surr_lm = sum u r_l r_m:
+//   d/dmu_l = sum_m A_lm sur_m (A symmetric) ;  d/dA_ll = -surr_ll / 2 + [use_det](sum u)/A_ll ;  d/dA_corr[l,m] = -surr_lm
+template <int D, int C, int K, bool IC = false>
 __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                                 float* __restrict__ acc) {
     using Lt = Layout<D, C, K>;
@@ -547,6 +612,26 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
         float* a = acc + k * Lt::PK;
         const bool act = R.act(k);
         const float su = a[Lt::O_PI];
+        if (IC) {
+            float sur[D];
+#pragma unroll
+            for (int l = 0; l < D; ++l) sur[l] = a[Lt::O_MU + l];
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                float gm = 0.0f;
+#pragma unroll
+                for (int m = 0; m < D; ++m) gm = fmaf((l >= m) ? R.A(k, l, m) : R.A(k, m, l), sur[m], gm);
+                a[Lt::O_MU + l] = gm;
+#pragma unroll
+                for (int m = 0; m <= l; ++m) {
+                    float v = (l == m) ? -0.5f * a[Lt::O_A + tri_index(l, m)] : -a[Lt::O_A + tri_index(l, m)];
+                    if (l == m && kc.use_det) v = fmaf(su, act ? fast_rcp(R.A(k, l, l)) : 0.0f, v);
+                    a[Lt::O_A + tri_index(l, m)] = v;
+                }
+            }
+            a[Lt::O_PI] = su * (act ? fast_rcp(R.pi(k)) : 0.0f);
+            continue;
+        }
         float suz[D];
 #pragma unroll
         for (int m = 0; m < D; ++m) suz[m] = a[Lt::O_MU + m] * SMOE_INV_SQ;
@@ -973,7 +1058,7 @@ __device__ __forceinline__ float ssim_block16(float* __restrict__ X, const float
 // ---------------------------------------------------------------------------
 // fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
 // ---------------------------------------------------------------------------
-template <int D, int C, int K, bool HAS_LW, int HL>
+template <int D, int C, int K, bool HAS_LW, int HL, bool IC = false>
 __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                                  const float* __restrict__ s_coords, const float* __restrict__ s_tgt,
                                                  const float* __restrict__ s_lw, int N, int G, int sub,
@@ -990,7 +1075,7 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
             for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
             const float lw = HAS_LW ? s_lw[n] : 1.0f;
             PixelOut<D, C, K> o;
-            pixel<D, C, K, true, HL>(R, kc, x, t, lw, acc, o);
+            pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o);
         }
     }
 }
@@ -1002,7 +1087,8 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // leaves the quantised reconstruction of the block in LDS, the wavefront turns it into dL/dq
 // (ssim_block), and the usual fused sweep runs with that gradient instead of the margin loss.
 // QUANT: quantization_mode 2 / 3 (all variables fake-quantised in the graph).
-template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false>
+// IC: train_inverse_cov (symmetric A, maha = r^T A r).
+template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false, bool IC = false>
 __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -1107,7 +1193,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             BlockRegs<D, C, K> R;
             R.load(s_par);
             if (has_quant) quantize_packed<D, C, K, QUANT>(R.P, kc);     // the graph sees the fake-quantised variables
-            R.derive(kc);
+            R.template derive<IC>(kc);
             frozen = R.frozen();
             if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
 #pragma unroll
@@ -1119,7 +1205,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     }
                 }
             }
-            if (HL > 0) hoist_const<D, C, K, HL>(R, xc);
+            if (HL > 0) hoist_const<D, C, K, HL, IC>(R, xc);
             if constexpr (SSIM) {
                 // the reference's SSIM branch does not use loss_weights (smoe.py:929-1010)
                 const int pxl = (N + G - 1) / G;
@@ -1134,7 +1220,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 #pragma unroll
                         for (int j = 0; j < Lt::NSLOT; ++j) scratch_acc[j] = 0.0f;
                         PixelOut<D, C, K> o;
-                        pixel<D, C, K, false, HL>(R, kc, x, t, 1.0f, scratch_acc, o);
+                        pixel<D, C, K, false, HL, false, IC>(R, kc, x, t, 1.0f, scratch_acc, o);
 #pragma unroll
                         for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
                     }
@@ -1151,20 +1237,20 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) { t[c] = s_tgt[c * N + n]; gq[c] = s_X[c * N + n]; }
                         PixelOut<D, C, K> o;
-                        pixel<D, C, K, true, HL, true>(R, kc, x, t, 1.0f, acc, o, gq);
+                        pixel<D, C, K, true, HL, true, IC>(R, kc, x, t, 1.0f, acc, o, gq);
                     }
                 }
             } else {
-                if (has_lw) pixel_loop_train<D, C, K, true, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
-                else pixel_loop_train<D, C, K, false, HL>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+                if (has_lw) pixel_loop_train<D, C, K, true, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+                else pixel_loop_train<D, C, K, false, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
             }
-            if (HL > 0) complete_const<D, C, K, HL>(xc, acc);
+            if (HL > 0) complete_const<D, C, K, HL, IC>(R, xc, acc);
         }
         {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
             R2.load(s_par);
             if (has_quant) quantize_packed<D, C, K, QUANT>(R2.P, kc);
-            finish_partials<D, C, K>(R2, kc, acc);
+            finish_partials<D, C, K, IC>(R2, kc, acc);
         }
         if constexpr (QUANT) if (kc.qmode == 3) {            // back through fake_quant_with_min_max_vars
             BlockRegs<D, C, K> R3;
@@ -1258,7 +1344,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 // ---------------------------------------------------------------------------
 // forward (evaluation) kernel
 // ---------------------------------------------------------------------------
-template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false>
+template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false, bool IC = false>
 __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -1320,7 +1406,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     BlockRegs<D, C, K> R;
     R.load(s_par);
     if (a.kc.qmode != 0 || a.kc.qpis != 0) quantize_packed<D, C, K, QUANT>(R.P, a.kc);
-    R.derive(a.kc);
+    R.template derive<IC>(a.kc);
 
     float acc[Lt::NSLOT];
 #pragma unroll
@@ -1337,7 +1423,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
             const float lw = has_lw ? s_lw[n] : 1.0f;
             PixelOut<D, C, K> o;
-            pixel<D, C, K, false>(R, a.kc, x, t, lw, acc, o);
+            pixel<D, C, K, false, 0, false, IC>(R, a.kc, x, t, lw, acc, o);
             if (SSIM) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
@@ -1458,9 +1544,15 @@ __global__ void readmit_quant_kernel(ReadmitArgs a, KernelConsts kc) {
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 float zz = 0.0f;
+                if (kc.inverse_cov) {                 // r^T A r with the symmetric A (smoe.py:791-793)
 #pragma unroll
-                for (int l = m; l < D; ++l) zz = fmaf(r[l], p[Lt::O_A + tri_index(l, m)], zz);
-                maha = fmaf(zz, zz, maha);
+                    for (int l = 0; l < D; ++l) zz = fmaf(r[l], (l >= m) ? p[Lt::O_A + tri_index(l, m)] : p[Lt::O_A + tri_index(m, l)], zz);
+                    maha = fmaf(zz, r[m], maha);
+                } else {
+#pragma unroll
+                    for (int l = m; l < D; ++l) zz = fmaf(r[l], p[Lt::O_A + tri_index(l, m)], zz);
+                    maha = fmaf(zz, zz, maha);
+                }
             }
             near = near || (maha < 800.0f);
         }
@@ -1510,10 +1602,14 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
-    auto kern = fit_kernel<D, C, K, G, WAVES, 0, false, true>;
+    const bool ic = a.kc.inverse_cov != 0;
+    auto kern = ic ? fit_kernel<D, C, K, G, WAVES, 0, false, true, true> : fit_kernel<D, C, K, G, WAVES, 0, false, true>;
     int hl = 0;
-    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, true>; hl = 1; }
-    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true>; hl = 2; }
+    if (hoist >= 1) { kern = ic ? fit_kernel<D, C, K, G, WAVES, 1, false, true, true> : fit_kernel<D, C, K, G, WAVES, 1, false, true>; hl = 1; }
+    if (D == 3 && hoist >= 2) {
+        kern = ic ? fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true, true> : fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true>;
+        hl = 2;
+    }
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
@@ -1526,7 +1622,36 @@ template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
-    auto kern = forward_kernel<D, C, K, G, WAVES, false, true>;
+    auto kern = a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, false, true, true> : forward_kernel<D, C, K, G, WAVES, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+// train_inverse_cov launches for the margin loss without mode-2/3 quantisation (the SSIM and QUANT launchers pick
+// their own IC instantiations)
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    auto kern = fit_kernel<D, C, K, G, WAVES, 0, false, false, true>;
+    int hl = 0;
+    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, false, true>; hl = 1; }
+    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, false, true>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + T::NB - 1) / T::NB;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    return hipGetLastError();
+}
+
+template <int D, int C, int K, int G, int WAVES>
+hipError_t launch_fwd_ic(const FwdArgs& a, hipStream_t st) {
+    using T = Tile<D, C, K, G, WAVES>;
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
+    auto kern = forward_kernel<D, C, K, G, WAVES, false, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1540,9 +1665,10 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
     if constexpr (D == 2) {
         using T = Tile<D, C, K, G, WAVES>;
         if (G == 16 && (a.bh != 16 || a.bw != 16 || hoist < 1)) return hipErrorNotSupported;   // register path: 16x16 only
-        auto kern = fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
+        const bool ic = a.kc.inverse_cov != 0;
+        auto kern = ic ? fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true, false, true> : fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
         int hl = (G == 16) ? 1 : 0;
-        if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
+        if (hoist >= 1) { kern = ic ? fit_kernel<D, C, K, G, WAVES, 1, true, false, true> : fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
         const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
@@ -1560,7 +1686,7 @@ hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
         using T = Tile<D, C, K, G, WAVES>;
         if (G == 16 && (a.bh != 16 || a.bw != 16)) return hipErrorNotSupported;
         const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw);
-        auto kern = forward_kernel<D, C, K, G, WAVES, true>;
+        auto kern = a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, false, true> : forward_kernel<D, C, K, G, WAVES, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1594,7 +1720,8 @@ int fit_occupancy(int N, bool has_lw) {
 #define SMOE_VARIANT(D, C, K, G, W) \
     { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
       &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W>, \
-      &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W> }
+      &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W>, \
+      &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W> }
 
 }  // namespace smoe
 #endif

@@ -277,6 +277,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     }
     fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
                       cfg->lower_bounds, cfg->upper_bounds);
+    kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;
     if (cfg->ssim_opt && !find_variant(h, 1, false)) {
         smoe_destroy(h);
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt planes of this block size do not fit in LDS");
@@ -345,6 +346,7 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1];
     if (h->cfg.ssim_opt) HIP_TRY(v->fwd_ssim(a, (hipStream_t)stream), "smoe_forward (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fwd_quant(a, (hipStream_t)stream), "smoe_forward (quantised) launch");
+    else if (h->kc.inverse_cov) HIP_TRY(v->fwd_ic(a, (hipStream_t)stream), "smoe_forward (inverse covariance) launch");
     else HIP_TRY(v->fwd(a, (hipStream_t)stream), "smoe_forward launch");
     return SMOE_OK;
 }
@@ -385,6 +387,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1];
     if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
+    else if (h->kc.inverse_cov) HIP_TRY(v->fit_ic(a, hoist, (hipStream_t)stream), "smoe_fit (inverse covariance) launch");
     else HIP_TRY(v->fit(a, hoist, (hipStream_t)stream), "smoe_fit launch");
     // TF multiplies the beta powers after every apply (fp32 running product)
     for (int i = 0; i < n_iters; ++i) {
@@ -404,6 +407,7 @@ int smoe_update_kernel_list(smoe_handle h, int32_t num_blocks, const smoe_params
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::ReadmitArgs a;
     a.p = *p; a.active = active; a.probes = h->d_probes; a.B = num_blocks; a.K = h->cfg.kernels;
+    a.inverse_cov = h->kc.inverse_cov;
     if (h->kc.qmode || h->kc.qpis) {                 // the probe test runs on the fake-quantised variables
         const smoe::Variant* v = find_variant(h, num_blocks, false);
         if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_update_kernel_list: no kernel variant");
@@ -596,6 +600,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;
     fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
                       cfg->lower_bounds, cfg->upper_bounds);
+    kc.inverse_cov = 0;                       // train_inverse_cov is not built for the shared-kernel mode
     *out = h;
     return SMOE_OK;
 }

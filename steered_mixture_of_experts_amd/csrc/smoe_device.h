@@ -31,6 +31,7 @@ struct KernelConsts {
     int q_musx;         // mode 3 quantises musX only when it is trained (smoe.py:515)
     float q_nmin[5], q_nmax[5], q_scale[5], q_inv[5];   // nudged fixed ranges (TF Nudge(), fp32)
     float q_levels[5];  // 2^bits - 1
+    int inverse_cov;    // train_inverse_cov (smoe.py:734-735,791-793): A symmetric, maha = r^T A r
 };
 
 struct FitArgs {
@@ -78,6 +79,7 @@ struct ReadmitArgs {
     uint32_t* active;
     const float* probes;      // [D][3] = {min, max, mid} per axis
     int B, K;
+    int inverse_cov;          // train_inverse_cov: maha = r^T A r
 };
 
 struct BestArgs {
@@ -109,6 +111,8 @@ struct Variant {
     hipError_t (*readmit_quant)(const ReadmitArgs&, const KernelConsts&, hipStream_t);   // fake-quantised graph
     hipError_t (*fit_quant)(const FitArgs&, int hoist_level, hipStream_t);               // quantization_mode 2 / 3
     hipError_t (*fwd_quant)(const FwdArgs&, hipStream_t);
+    hipError_t (*fit_ic)(const FitArgs&, int hoist_level, hipStream_t);                  // train_inverse_cov
+    hipError_t (*fwd_ic)(const FwdArgs&, hipStream_t);
 };
 
 // ---- shared-kernel image mode (smoe_shared.hip) ----------------------------------------------

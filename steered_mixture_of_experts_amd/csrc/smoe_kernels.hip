@@ -40,9 +40,15 @@ __global__ void readmit_kernel(ReadmitArgs a) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             float zz = 0.0f;
+            if (a.inverse_cov) {                      // r^T A r with the symmetric A (smoe.py:791-793)
 #pragma unroll
-            for (int l = m; l < D; ++l) zz = fmaf(r[l], A[l][m], zz);
-            maha = fmaf(zz, zz, maha);
+                for (int l = 0; l < D; ++l) zz = fmaf(r[l], (l >= m) ? A[l][m] : A[m][l], zz);
+                maha = fmaf(zz, r[m], maha);
+            } else {
+#pragma unroll
+                for (int l = m; l < D; ++l) zz = fmaf(r[l], A[l][m], zz);
+                maha = fmaf(zz, zz, maha);
+            }
         }
         near = near || (maha < 800.0f);
     }

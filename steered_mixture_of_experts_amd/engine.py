@@ -48,6 +48,7 @@ class EngineConfig:
     bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
     lower_bounds: Sequence[float] = (-2500, -.3, -5, 0, -32)
     upper_bounds: Sequence[float] = (2500, 1.3, 5, 2, 32)
+    train_inverse_cov: bool = False      # smoe.py:734-735,791-793 (reference ctor default True, CLI default False)
 
     @property
     def dim(self) -> int:
@@ -116,6 +117,7 @@ class BlockEngine:
         for i in range(5):
             c.bit_depths[i] = int(cfg.bit_depths[i])
             c.lower_bounds[i], c.upper_bounds[i] = float(cfg.lower_bounds[i]), float(cfg.upper_bounds[i])
+        c.train_inverse_cov = int(cfg.train_inverse_cov)
         self._c = c
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_create(C.byref(self._h), C.byref(c)))

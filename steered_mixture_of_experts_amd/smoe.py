@@ -66,12 +66,12 @@ class Smoe:
                  quantize_pis=False, lower_bounds=None, upper_bounds=None, use_yuv=True, only_y_gamma=False,
                  ssim_opt=False, precision=8, add_kernel_slots=0, iter_offset=0, margin=0.5,
                  overlap_of_batches=0, kernel_count_as_norm_l1=False, train_svs=False, affines=None,
-                 train_trafo=False, num_params_model=6, train_inverse_cov=False, init_flag=1,
+                 train_trafo=False, num_params_model=6, train_inverse_cov=True, init_flag=1,
                  only_rec_from_checkpoint=False, loss_mask=None, device=None, engine_factory=None):
         # -- options outside the hot path: refuse loudly ---------------------------------
         unsupported = {
             "radial_as": radial_as,
-            "train_svs": train_svs, "train_trafo": train_trafo, "train_inverse_cov": train_inverse_cov,
+            "train_svs": train_svs, "train_trafo": train_trafo,
             "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
         }
         for name, val in unsupported.items():
@@ -248,7 +248,7 @@ class Smoe:
             start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma), ssim_opt=bool(self.ssim_opt),
             quantization_mode=int(self.quantization_mode), quantize_pis=bool(self.quantize_pis),
             bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
-            upper_bounds=tuple(self.upper_bounds))
+            upper_bounds=tuple(self.upper_bounds), train_inverse_cov=bool(self.train_inverse_cov))
         key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
         key = repr(key)
         if key != self._engine_key:

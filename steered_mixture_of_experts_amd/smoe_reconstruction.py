@@ -21,7 +21,8 @@ def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6
         os.mkdir(results_path)
     smoe = Smoe(orig, init_params=init_params, start_batches=batches, batch_size=list(cp['batch_size']),
                 bit_depths=list(bit_depths), precision=precision,
-                use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)))
+                use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)),
+                train_inverse_cov=bool(cp.get('train_inverse_cov', False)))     # absent key: trained by the CLI (False)
     smoe.quantization_mode = cp.get('quantization_mode') or 0          # smoe_reconstruction.py:32-43
     smoe.quantize_pis = bool(cp.get('quantized_pis'))
     smoe.lower_bounds, smoe.upper_bounds = cp.get('lower_bounds'), cp.get('upper_bounds')

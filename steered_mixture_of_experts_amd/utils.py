@@ -25,7 +25,9 @@ def save_model(smoe, path, best=False, reduce=False, quantize=False):
           'lower_bounds': smoe.lower_bounds, 'upper_bounds': smoe.upper_bounds,
           'use_yuv': smoe.use_yuv, 'only_y_gamma': smoe.only_y_gamma, 'ssim_opt': smoe.ssim_opt,
           'use_determinant': smoe.use_determinant, 'use_diff_center': smoe.use_diff_center,
-          # additions needed to rebuild the block tiling
+          # additions needed to rebuild the block tiling and the form of the kernels (the reference's Smoe defaults to
+          # train_inverse_cov=True while its CLI trains with False, smoe.py:41 / smoe_test.py:342)
+          'train_inverse_cov': bool(getattr(smoe, 'train_inverse_cov', False)),
           'batch_size': tuple(smoe.batch_size_valued), 'shape_of_img': tuple(smoe.image.shape)}
     if quantize:                                                     # utils.py:37-56
         qparams = dict(smoe.qparams)

@@ -24,7 +24,7 @@ if ws > 1:
     dist.init_process_group(backend="gloo")
 b = blk.synthetic_blocks(15, (16, 16), 1, 99)
 img = blk.blocks_to_image(b, (48, 80), (16, 16))
-s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine)
+s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine)
 s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
 s.train(6, val_iter=3)
 out = {"params": s.get_params(), "losses": s.get_losses(), "mses": s.get_mses(), "num_pis": s.get_num_pis(),

@@ -19,7 +19,7 @@ def _image(h, w, C=1, seed=0):
 
 
 def _make(img, **kw):
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     return s
 
@@ -59,7 +59,7 @@ def test_train_matches_the_numpy_restatement():
 
 def test_single_block_is_configs0():
     img = blk.synthetic_blocks(1, (16, 16), 1, 7)[0]
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[None], use_determinant=True, engine_factory=OracleEngine)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[None], use_determinant=True, engine_factory=OracleEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     assert s.num_blocks == 1 and s.batch_size_valued == (16, 16)
     loss, mse, num_pi, num_sv = s.run_batched(train=False, update_reconstruction=True)
@@ -71,13 +71,13 @@ def test_single_block_is_configs0():
 
 def test_padded_image_and_loss_mask():
     img = _image(40, 37, C=3, seed=3)
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True,
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True,
              engine_factory=OracleEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     assert s.padded and s.num_blocks == 9 and s.use_yuv
     s.train(4, val_iter=2)
     assert s.get_reconstruction().shape == (40, 37, 3)
-    g = Smoe(img[..., :1], kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
+    g = Smoe(img[..., :1], train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
     assert not g.use_yuv                      # forced off unless C == 3 (smoe_test.py:41-44)
 
 
@@ -101,7 +101,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
     cp = utils.load_checkpoint(mp)
     assert set(cp) >= {"params", "mses", "losses", "num_pis", "use_yuv", "use_determinant", "batch_size"}
     assert np.array_equal(utils.load_params(mp)["nu_e"], after["nu_e"])
-    r = Smoe(img, init_params=cp["params"], batch_size=list(cp["batch_size"]), use_determinant=True,
+    r = Smoe(img, train_inverse_cov=False, init_params=cp["params"], batch_size=list(cp["batch_size"]), use_determinant=True,
              engine_factory=OracleEngine)
     assert np.array_equal(r.get_reconstruction(), s.get_reconstruction())
 
@@ -109,15 +109,15 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
     for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True},
-               {"train_inverse_cov": True}, {"quantization_mode": 3, "use_diff_center": True},
+               {"quantization_mode": 3, "use_diff_center": True},
                {"quantization_mode": 2, "ssim_opt": True}):
         with pytest.raises(NotImplementedError):
-            Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
+            Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
     with pytest.raises(AssertionError):
-        Smoe(img, batch_size=[16, 16], engine_factory=OracleEngine)
+        Smoe(img, train_inverse_cov=False, batch_size=[16, 16], engine_factory=OracleEngine)
     with pytest.raises(ValueError):
-        Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16, 4], engine_factory=OracleEngine)
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
+        Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16, 4], engine_factory=OracleEngine)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
     with pytest.raises(AssertionError):
         s.train(1)                               # "no optimizer found" (smoe.py:1492)
     assert utils.psnr(65536.0 * 1e-3, 8) == pytest.approx(30.0)
@@ -127,7 +127,7 @@ def test_quantizer_matches_per_block_transcription_and_mode1_training():
     from quantizer_ref import quantize_block
     from steered_mixture_of_experts_amd.quantizer import quantize_params, rescaler
     img = _image(48, 32)
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=1,
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=1,
              bit_depths=[20, 18, 6, 10, 10], engine_factory=OracleEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     s.train(6, val_iter=3)
@@ -236,15 +236,15 @@ def test_shared_facade_with_overlapping_batches():
 
 def test_start_batches_selects_the_block_shape():
     img = _image(64, 64)
-    s = Smoe(img, kernels_per_dim=[2, 2], start_batches=16, batch_size=[None], engine_factory=OracleEngine)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], start_batches=16, batch_size=[None], engine_factory=OracleEngine)
     assert s.batch_size_valued == (16, 16) and s.num_blocks == 16            # get_batch_shape, smoe.py:229,243
-    s1 = Smoe(img[:16, :16], kernels_per_dim=[2, 2], engine_factory=OracleEngine)
+    s1 = Smoe(img[:16, :16], train_inverse_cov=False, kernels_per_dim=[2, 2], engine_factory=OracleEngine)
     assert s1.batch_size_valued == (16, 16) and s1.num_blocks == 1
 
 
 def test_only_y_gamma_and_use_diff_center():
     img = _image(32, 32, C=3, seed=9)
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, only_y_gamma=True,
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, only_y_gamma=True,
              use_diff_center=True, engine_factory=OracleEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     assert s.only_y_gamma and np.array_equal(s.get_params()["musX"], np.zeros((4, 4, 2), np.float32))
@@ -253,14 +253,14 @@ def test_only_y_gamma_and_use_diff_center():
     assert np.abs(p["gamma_e"][..., 0]).max() > 0 and not p["gamma_e"][..., 1:].any()      # smoe.py:725-729
     assert 0 < np.abs(p["musX"]).max() < 0.05                                               # offsets, not centres
     # the same fit without use_diff_center: centres = grid + offsets
-    t = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, only_y_gamma=True,
+    t = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, only_y_gamma=True,
              engine_factory=OracleEngine)
     t.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     t.train(6, val_iter=3)
     grid = blk.gen_domain_grid([2, 2], 2).astype(np.float32)
     assert np.allclose(t.get_params()["musX"], grid[None] + p["musX"], atol=1e-7)
     # only_y_gamma is dropped when the image is not YUV (smoe_test.py:41-44)
-    g = Smoe(img[..., :1], kernels_per_dim=[2, 2], batch_size=[16, 16], only_y_gamma=True, engine_factory=OracleEngine)
+    g = Smoe(img[..., :1], train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], only_y_gamma=True, engine_factory=OracleEngine)
     assert not g.only_y_gamma
 
 
@@ -305,7 +305,7 @@ def test_training_cli_mirrors_the_reference_flags(tmp_path):
 def test_ssim_opt_fits_one_minus_ssim():
     """ssim_opt (smoe.py:929,980-1011): the facade trains on 1 - SSIM; losses follow oracle.fit with ssim_opt."""
     img = _image(32, 32, seed=12)
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, ssim_opt=True,
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, ssim_opt=True,
              engine_factory=OracleEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
     s.train(6, val_iter=3)
@@ -320,10 +320,10 @@ def test_ssim_opt_fits_one_minus_ssim():
     assert 0.0 < losses[-1] < losses[0] < 1.0
     for kw in ({"loss_mask": np.ones((32, 32), np.float32)}, {"batch_size": [12, 12]}):
         with pytest.raises(NotImplementedError):
-            Smoe(img, **{"kernels_per_dim": [2, 2], "batch_size": [16, 16], "ssim_opt": True,
+            Smoe(img, train_inverse_cov=False, **{"kernels_per_dim": [2, 2], "batch_size": [16, 16], "ssim_opt": True,
                          "engine_factory": OracleEngine, **kw})
     with pytest.raises(ValueError):
-        Smoe(img, kernels_per_dim=[2, 2], batch_size=[4, 16], ssim_opt=True, engine_factory=OracleEngine)
+        Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[4, 16], ssim_opt=True, engine_factory=OracleEngine)
 
 
 @pytest.mark.parametrize("mode,qpis", [(0, True), (2, False), (3, False)])
@@ -334,7 +334,7 @@ def test_fake_quantised_fit_through_the_facade(mode, qpis):
     img = _image(32, 32, seed=3)
     kw = dict(quantization_mode=mode, quantize_pis=qpis, bit_depths=[14, 12, 8, 10, 10],
               lower_bounds=[-60, -.3, -1, 0, -4], upper_bounds=[60, 1.3, 2, 2, 4])
-    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
     assert s.quantize_pis                                     # implied by modes >= 2 (smoe_test.py:36-37)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
     s.train(6, val_iter=3)
@@ -353,7 +353,7 @@ def test_fake_quantised_fit_through_the_facade(mode, qpis):
     # a kernel whose pi rounds to 0 on the 10-bit lattice of [0, 2] is not counted (pis_mask = qpis > 0)
     p = s.get_params()
     p["pis"][0, 0] = 0.0004
-    s2 = Smoe(img, init_params=p, batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
+    s2 = Smoe(img, train_inverse_cov=False, init_params=p, batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine, **kw)
     s2.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
     assert s2.run_batched(train=False)[2] == 15
 
@@ -407,3 +407,35 @@ def test_shared_facade_only_y_gamma_and_diff_center():
     pn, _, _ = o.shared_fit(p0, tb.reshape(4, -1, 3), o.global_batch_coords((32, 32), (16, 16)), cfg, 4, val_iter=2)
     assert np.allclose(p["musX"] + p0["musX"][0], pn["musX"][0], atol=2e-6)
     assert np.allclose(p["nu_e"], pn["nu_e"][0], atol=2e-6)
+
+
+def test_inverse_covariance_fit_through_the_facade():
+    """train_inverse_cov=True (the reference constructor default): A_init is squared (smoe.py:2162), the fit
+    follows oracle.fit with the symmetric form."""
+    img = _image(32, 32, seed=8)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, train_inverse_cov=True,
+             engine_factory=OracleEngine)
+    assert np.allclose(np.diagonal(s.get_params()["A_diagonal"], axis1=-2, axis2=-1), 36.0)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    s.train(6, val_iter=3)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4, lr_steer=0.05, train_inverse_cov=True)
+    p0 = o.init_params(tb, [2, 2])
+    p0["A_diagonal"] = p0["A_diagonal"] ** 2
+    pn, _, info = o.fit(p0, tb.reshape(4, -1, 1), o.block_coords((16, 16)), cfg, 6, val_iter=3, dtype=np.float32)
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k], rtol=1e-5, atol=2e-6), k
+    assert s.get_losses()[-1][1] < s.get_losses()[0][1]
+
+
+def test_constructor_default_is_the_references_inverse_covariance_form():
+    """smoe.py:41: Smoe(...) defaults to train_inverse_cov=True (the CLI passes False, smoe_test.py:342); a saved model
+    records the form and smoe_reconstruction rebuilds with it."""
+    img = _image(16, 16)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine)
+    assert s.train_inverse_cov and np.allclose(np.diagonal(s.get_params()["A_diagonal"], axis1=-2, axis2=-1), 36.0)
+    q = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], ssim_opt=True, quantize_pis=True, engine_factory=OracleEngine)
+    q.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    q.train(2, val_iter=1)                                   # the default form composes with the SSIM loss
+    assert 0 < q.get_losses()[-1][1] < 1

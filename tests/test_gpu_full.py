@@ -70,7 +70,7 @@ def test_facade_on_gpu_matches_facade_on_the_c_oracle():
     img = blk.blocks_to_image(b, (96, 128), (16, 16))
 
     def run(factory):
-        s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=factory)
+        s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=factory)
         s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
         s.train(10, val_iter=5)
         return s
@@ -243,7 +243,7 @@ def test_end_to_end_fit_quality_on_a_smooth_image():
         img += a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
     img += 0.2 * (xx + 0.5 * yy > 0.9) + rng.normal(scale=1.5 / 255, size=img.shape)
     img = (np.round(np.clip(img, 0, 1) * 255).astype(np.uint8).astype(np.float32) / np.float32(255.))[..., None]
-    b = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True)
+    b = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True)
     b.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
     p0 = b.get_psnr()
     b.train(300, val_iter=100)

@@ -1,0 +1,161 @@
+"""GPU parity of train_inverse_cov (the reference CONSTRUCTOR default; smoe.py:734-735,791-793): A symmetric
+(diag + A_corr + A_corr^T), maha = r^T A r, determinant factor prod(diag A) -- against the CPU restatement
+(checked against torch.autograd in tests/test_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import smoe_oracle as o
+from test_gpu_parity import SHAPES, _bits_to_mask, _close, _engine, _mask_to_bits, _planar, _setup, _to_dev, _to_host
+
+pytestmark = pytest.mark.gpu
+
+
+def _ic_setup(shape, C, kpd, yuv, B, seed, **kw):
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, seed, train_inverse_cov=True, **kw)
+    # generate_kernel_grid squares A_init for this form (smoe.py:2162); keep the matrices positive definite
+    p["A_diagonal"] = (p["A_diagonal"] ** 2).astype(np.float32)
+    p["A_corr"] = (p["A_corr"] * 2.0).astype(np.float32)
+    return cfg, p, coords, tgt, K
+
+
+@pytest.mark.parametrize("shape,C,kpd,yuv", SHAPES)
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_invcov_forward(shape, C, kpd, yuv, tiling):
+    B = 29
+    cfg, p, coords, tgt, K = _ic_setup(shape, C, kpd, yuv, B, 500 + C, pis_l1=0.2, u_l1=0.003)
+    active = np.random.default_rng(3).uniform(size=(B, K)) < 0.9
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32)
+    ref64 = o.forward(p, tgt, coords, active, cfg, None, np.float64)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.2, u_l1=0.003, train_inverse_cov=True)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    out = eng.forward(_planar(tgt), dp, act, want_recon=True, want_gate=True)
+    torch.cuda.synchronize()
+    gate = out["gate_w"].cpu().numpy()
+    near_tau = np.abs(ref64["w"] - 0.5 / 256) < 1e-6
+    assert (_close(gate, ref["wt"], rtol=2e-5) | near_tau).all(), np.abs(gate - ref["wt"]).max()
+    recon = np.transpose(out["recon"].cpu().numpy(), (0, 2, 1))
+    frac = (np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie = (frac < 3e-4) | (frac > 1 - 3e-4)
+    assert (np.abs(recon - ref["recon"])[~tie] < 1e-7).all()
+    refq = o.forward(p, tgt, coords, active, cfg, None, np.float32, q_override=recon)
+    assert _close(out["loss"].cpu().numpy(), refq["loss"], rtol=3e-5).all()
+    new_act = _bits_to_mask(act.cpu().numpy().view(np.uint32), K)
+    assert (new_act == ref["active_new"])[~near_tau.any(axis=2)].all()
+    # it really is the other form
+    std = o.forward(p, tgt, coords, active, o.OracleConfig(**{**cfg.__dict__, "train_inverse_cov": False}), None, np.float32)
+    assert np.abs(std["wt"] - ref["wt"]).max() > 1e-2
+    eng.close()
+
+
+@pytest.mark.parametrize("shape,C,kpd,yuv", SHAPES)
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_invcov_one_step_gradients(shape, C, kpd, yuv, tiling):
+    B = 21
+    cfg, p, coords, tgt, K = _ic_setup(shape, C, kpd, yuv, B, 700 + C, pis_l1=0.05, u_l1=0.001)
+    active = np.ones((B, K), dtype=bool)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.05, u_l1=0.001, train_inverse_cov=True)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref64 = o.forward(p, tgt, coords, active, cfg, None, np.float64, want_grads=True, q_override=recon)
+    state = eng.new_adam_state(dp)
+    loss = torch.zeros(B, device="cuda")
+    eng.fit(T, dp, state, act, 1, loss_out=loss)
+    torch.cuda.synchronize()
+    tie = (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    edge = ((np.abs(ref64["y"]) < 1e-6) | (np.abs(ref64["y"] - 1) < 1e-6)).any(axis=(1, 2))
+    clean = ~(tie | edge)
+    assert clean.sum() >= B // 2
+    assert _close(loss.cpu().numpy()[clean], ref64["loss"][clean], rtol=3e-5).all()
+    m = _to_host(state.m)
+    for name in o.PARAM_NAMES:
+        g_ref = ref64["grads"][name][clean]
+        scale = np.abs(g_ref).max() + 1e-30
+        err = np.abs(m[name][clean] / 0.1 - g_ref).max() / scale
+        assert err < 3e-5, (name, err)
+    eng.close()
+
+
+def test_invcov_gentle_fit_and_readmission():
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 64
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 991, perturb=False, lr_steer=0.05, train_inverse_cov=True)
+    p["A_diagonal"] = p["A_diagonal"] ** 2
+    n = 40
+    p32, _, i32 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float32)
+    p64, _, _ = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float64)
+    eng = _engine(shape, C, K, lr_steer=0.05, train_inverse_cov=True)
+    dp = _to_dev(p)
+    state = eng.new_adam_state(dp)
+    act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
+    T = _planar(tgt)
+    l0 = eng.forward(T, dp, act, want_recon=False)["loss"].cpu().numpy()
+    eng.fit(T, dp, state, act, n)
+    l1 = eng.forward(T, dp, act, want_recon=False, update_active=False)["loss"].cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.median(l1) < 0.7 * np.median(l0)
+    got = _to_host(dp)
+    for name in o.PARAM_NAMES:
+        dev = np.abs(got[name] - p32[name])
+        floor = np.abs(p32[name] - p64[name])
+        assert np.median(dev) <= 3 * np.median(floor) + 1e-5, (name, np.median(dev), np.median(floor))
+    pp = {k: v.copy() for k, v in got.items()}
+    pp["A_diagonal"][5] *= 900.0
+    want = o.readmit(pp, np.zeros((B, K), bool), cfg, np.float32)
+    empty = torch.zeros_like(act)
+    eng.update_kernel_list(_to_dev(pp), empty)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits_to_mask(empty.cpu().numpy().view(np.uint32), K), want) and not want[5].all()
+    eng.close()
+
+
+def test_invcov_facade_and_refused_combinations():
+    from fake_engine import OracleEngine
+    from steered_mixture_of_experts_amd import _lib
+    from steered_mixture_of_experts_amd import blocks as blk
+    from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
+    from steered_mixture_of_experts_amd.smoe import Adam, Smoe
+    b = blk.synthetic_blocks(16, (16, 16), 1, 9)
+    img = blk.blocks_to_image(b, (64, 64), (16, 16))
+    runs = []
+    for factory in (None, OracleEngine):
+        s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, train_inverse_cov=True,
+                 **({} if factory is None else {"engine_factory": factory}))
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+        s.train(20, val_iter=10)
+        runs.append([v for _, v in s.get_losses()])
+    assert abs(runs[0][0] - runs[1][0]) < 1e-6 * runs[1][0] + 1e-9 and np.allclose(runs[0], runs[1], rtol=2e-2)
+    assert runs[0][-1] < runs[0][0]
+    # the form composes with the SSIM loss and the fake-quantised graph: one-step gradients against the oracle
+    for kw in ({"ssim_opt": True}, {"quantization_mode": 3, "quantize_pis": True, "bit_depths": (14, 12, 8, 10, 10)},
+               {"quantization_mode": 2, "quantize_pis": True, "bit_depths": (16, 12, 8, 10, 10),
+                "lower_bounds": (-200, -.3, -1, 0, -4), "upper_bounds": (200, 1.3, 2, 2, 4)}):
+        B = 17
+        cfg, p, coords, tgt, K = _ic_setup((16, 16), 1, [2, 2], False, B, 41, **kw)
+        d = 2
+        p["A_corr"] = p["A_corr"] * np.tril(np.ones((d, d), np.float32), -1)
+        active = np.ones((B, K), bool)
+        eng = _engine((16, 16), 1, K, train_inverse_cov=True, **kw)
+        dp = _to_dev(p)
+        act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+        T = _planar(tgt)
+        recon = np.transpose(eng.forward(T, dp, act, want_recon=True, update_active=False)["recon"].cpu().numpy(), (0, 2, 1))
+        ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True, q_override=recon)
+        st = eng.new_adam_state(dp)
+        eng.fit(T, dp, st, act, 1)
+        torch.cuda.synchronize()
+        tie = (np.abs(ref["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+        edge = ((np.abs(ref["y"]) < 1e-6) | (np.abs(ref["y"] - 1) < 1e-6)).any(axis=(1, 2))
+        clean = ~(tie | edge)
+        m = _to_host(st.m)
+        for name in o.PARAM_NAMES:
+            g_ref = ref["grads"][name][clean]
+            err = np.abs(m[name][clean] / 0.1 - g_ref).max() / (np.abs(g_ref).max() + 1e-30)
+            assert err < 1e-4, (kw, name, err)
+        eng.close()

@@ -160,7 +160,7 @@ def test_quant_facade_on_gpu_follows_the_oracle_backed_facade():
     for mode in (0, 3):
         runs = []
         for factory in (None, OracleEngine):
-            s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=mode,
+            s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=mode,
                      quantize_pis=True, bit_depths=list(QKW["bit_depths"]), lower_bounds=list(QKW["lower_bounds"]),
                      upper_bounds=list(QKW["upper_bounds"]), **({} if factory is None else {"engine_factory": factory}))
             s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))

@@ -154,7 +154,7 @@ def test_ssim_facade_on_gpu_follows_the_oracle_backed_facade():
     img = blk.blocks_to_image(b, (64, 64), (16, 16))
     runs = []
     for factory in (None, OracleEngine):
-        s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, ssim_opt=True,
+        s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_yuv=True, ssim_opt=True,
                  **({} if factory is None else {"engine_factory": factory}))
         s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
         s.train(20, val_iter=10)
