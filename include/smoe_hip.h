@@ -87,6 +87,9 @@ typedef struct smoe_config {
     int32_t train_inverse_cov;  /* A symmetric (diag + A_corr + A_corr^T), maha = r^T A r; the determinant factor keeps
                                    prod(diag A).  Reference CONSTRUCTOR default True, CLI default False
                                    (smoe.py:41,734-735,791-793; smoe_test.py:342)                               */
+    int32_t radial_as;          /* one steering value per kernel (A = a I): the caller keeps A_diagonal [B,K,d,d] with equal
+                                   diagonal entries (and equal Adam slots); their gradient is the trace of dL/dA, A_corr
+                                   is not trained                                    smoe.py:349-365,429-434,714-719 */
 } smoe_config;
 
 /* Parameter set in the reference's get_params() layout (smoe.py:1795-1800) with a

@@ -72,6 +72,8 @@ class OracleConfig:
     # fake-quantised parameters inside the graph (smoe.py:474-538); order of the 5-tuples: A, musX, nu_e, pis, gamma_e
     train_inverse_cov: bool = False       # smoe.py:734-735,791-793: A symmetric, maha = r^T A r (the ctor default is
                                           # True, the CLI default False, smoe_test.py:342)
+    radial_as: bool = False               # smoe.py:349-365,429-434,714-719: ONE steering value per kernel (A = a I),
+                                          # A_corr not trainable.  Held here as A_diagonal with equal diagonal entries
     quantization_mode: int = 0            # 0/1: none in the graph; 2: fixed ranges; 3: min/max of the model's kernels
     quantize_pis: bool = False            # smoe.py:474 (the reference CLI passes True by default, smoe_test.py:304)
     bit_depths: Tuple[int, ...] = (20, 18, 6, 10, 10)                 # smoe_test.py:302
@@ -531,6 +533,10 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     low = np.tril(np.ones((d, d), dtype=bool), -1)
     g_Adiag = np.where(eye, g_A, T(0))
     g_Acorr = np.where(low, g_A, T(0))
+    if cfg.radial_as:       # a is tiled over the diagonal (smoe.py:714-719): dL/da = sum_l dL/dA_ll, kept on every diagonal entry
+        tr = np.trace(g_Adiag, axis1=-2, axis2=-1)[..., None, None]
+        g_Adiag = np.where(eye, tr, T(0)).astype(T)
+        g_Acorr = np.zeros_like(g_Acorr)                    # A_corr_var is not trainable (smoe.py:434)
     # centres: dm/dmu = -2 A z
     Az = z if ic else np.einsum("bklm,bknm->bknl", A, z)    # dm/dmu = -2 A r (symmetric A) resp. -2 A A^T r
     g_mu = np.einsum("bkn,bknl->bkl", u, Az)
@@ -560,7 +566,7 @@ def adam_step(p, grads, state, cfg: OracleConfig, dtype=np.float32, frozen=None)
     groups = {
         "nu_e": (cfg.lr_expert, True), "gamma_e": (cfg.lr_expert, cfg.train_gammas),
         "musX": (cfg.lr_expert, cfg.train_musx), "pis": (cfg.lr_pis, cfg.train_pis),
-        "A_diagonal": (cfg.lr_steer, True), "A_corr": (cfg.lr_steer, True),
+        "A_diagonal": (cfg.lr_steer, True), "A_corr": (cfg.lr_steer, not cfg.radial_as),
     }
     newp = {}
     for name in PARAM_NAMES:

@@ -601,6 +601,18 @@ __device__ __forceinline__ void complete_const(const BlockRegs<D, C, K>& R, cons
 //   d/dpi   = (sum u) / pi
 //   d/dmu_l = sum_m A[l][m] suz_m                        (dm/dmu = -2 A z, dL/dm = -u/2)
 //   d/dA_lm = -(sxz_lm - mu_l suz_m) + [l==m, use_det] (sum u)/A_ll
+// radial_as (smoe.py:714-719): one steering value per kernel tiled over the diagonal -> its gradient is the trace of
+// dL/dA; every diagonal slot receives it so that the d copies of the variable (and their Adam slots) stay equal.
+template <int D, int C, int K>
+__device__ __forceinline__ void tie_diagonal(float* __restrict__ a) {
+    using Lt = Layout<D, C, K>;
+    float tr = 0.0f;
+#pragma unroll
+    for (int l = 0; l < D; ++l) tr += a[Lt::O_A + tri_index(l, l)];
+#pragma unroll
+    for (int l = 0; l < D; ++l) a[Lt::O_A + tri_index(l, l)] = tr;
+}
+
 //   train_inverse_cov (IC), raw sums sur_l = sum u r_l, surr_lm = sum u r_l r_m:
 //   d/dmu_l = sum_m A_lm sur_m (A symmetric) ;  d/dA_ll = -surr_ll / 2 + [use_det](sum u)/A_ll ;  d/dA_corr[l,m] = -surr_lm
 template <int D, int C, int K, bool IC = false>
@@ -630,6 +642,7 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
                 }
             }
             a[Lt::O_PI] = su * (act ? fast_rcp(R.pi(k)) : 0.0f);
+            if (kc.radial) tie_diagonal<D, C, K>(a);
             continue;
         }
         float suz[D];
@@ -652,6 +665,7 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
             }
         }
         a[Lt::O_PI] = su * (act ? fast_rcp(R.pi(k)) : 0.0f);
+        if (kc.radial) tie_diagonal<D, C, K>(a);
     }
 }
 
@@ -1159,8 +1173,10 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             if (tensor == 1 && !a.train_musx) r = 0.0f;
             if (tensor == 4 && !a.kc.train_gammas) r = 0.0f;
             if (tensor == 4 && a.kc.only_y_gamma && (off % C) != 0) r = 0.0f;   // masked slopes get zero gradient
+            if (tensor == 3 && a.kc.radial) r = 0.0f;                           // radial_as: A_corr is not trainable (smoe.py:434)
             lr[s] = r;
-            reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? a.reg_u : 0.0f);   // smoe.py:1027,1044
+            // smoe.py:1027,1044; radial_as: u_l1 * sum(diag A) = u_l1 * d * a, and the d tied slots each carry dL/da
+            reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? (a.kc.radial ? a.reg_u * (float)D : a.reg_u) : 0.0f);
             // fixed-range fake quant of this variable: the gradient passes inside the nudged range only
             const int qg = (tensor == 0) ? 3 : ((tensor == 1) ? 1 : ((tensor == 4) ? 4 : ((tensor == 5) ? 2 : 0)));
             if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) { qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; }

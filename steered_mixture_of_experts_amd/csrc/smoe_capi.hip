@@ -177,6 +177,8 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
                                            cfg->upper_bounds, &qmsg);
         if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_create: ") + qmsg);
     }
+    if (cfg->radial_as && cfg->quantization_mode == 3)
+        return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built");
     if (cfg->ssim_opt && cfg->quantization_mode >= 2)
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt together with quantization_mode 2/3 is not instantiated");
     if (cfg->ssim_opt) {
@@ -278,6 +280,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
                       cfg->lower_bounds, cfg->upper_bounds);
     kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;
+    kc.radial = cfg->radial_as ? 1 : 0;
     if (cfg->ssim_opt && !find_variant(h, 1, false)) {
         smoe_destroy(h);
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt planes of this block size do not fit in LDS");
@@ -600,7 +603,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;
     fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
                       cfg->lower_bounds, cfg->upper_bounds);
-    kc.inverse_cov = 0;                       // train_inverse_cov is not built for the shared-kernel mode
+    kc.inverse_cov = 0;                       // train_inverse_cov / radial_as are not built for the shared-kernel mode
+    kc.radial = 0;
     *out = h;
     return SMOE_OK;
 }

@@ -32,6 +32,7 @@ struct KernelConsts {
     float q_nmin[5], q_nmax[5], q_scale[5], q_inv[5];   // nudged fixed ranges (TF Nudge(), fp32)
     float q_levels[5];  // 2^bits - 1
     int inverse_cov;    // train_inverse_cov (smoe.py:734-735,791-793): A symmetric, maha = r^T A r
+    int radial;         // radial_as (smoe.py:714-719): the steering diagonal is one value per kernel
 };
 
 struct FitArgs {

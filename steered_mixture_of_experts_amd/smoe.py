@@ -70,7 +70,7 @@ class Smoe:
                  only_rec_from_checkpoint=False, loss_mask=None, device=None, engine_factory=None):
         # -- options outside the hot path: refuse loudly ---------------------------------
         unsupported = {
-            "radial_as": radial_as,
+
             "train_svs": train_svs, "train_trafo": train_trafo,
             "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
         }
@@ -84,6 +84,9 @@ class Smoe:
                                       "are not built: the engine works on absolute centres")
         if quantization_mode >= 2 and ssim_opt:
             raise NotImplementedError("ssim_opt together with quantization_mode 2/3 is not instantiated")
+        if radial_as and quantization_mode >= 1:
+            raise NotImplementedError("radial_as with a quantization mode (own range formulas, smoe.py:498-504, "
+                                      "quantizer.py) is not built")
         if add_kernel_slots:
             raise NotImplementedError("progressive kernel adding changes K over time; not part of the hot path")
         if overlap_of_batches:
@@ -164,6 +167,8 @@ class Smoe:
         # -- initial parameters (smoe.py:252-262) ----------------------------------------
         if init_params:
             p0 = {k: np.asarray(init_params[k], dtype=np.float32) for k in PARAM_NAMES}
+            if radial_as and p0["A_diagonal"].ndim == p0["pis"].ndim:        # the reference's (K,) variable (smoe.py:429-433)
+                p0["A_diagonal"] = p0["A_diagonal"][..., None, None] * np.eye(d, dtype=np.float32)
             if p0["pis"].ndim == 1:                       # a single block's dict: broadcast
                 p0 = {k: np.broadcast_to(v, (self.num_blocks,) + v.shape).copy() for k, v in p0.items()}
             if p0["pis"].shape[0] != self.num_blocks:
@@ -178,6 +183,11 @@ class Smoe:
             p0 = blk.init_block_params(blocks_local, kpd, normalize_pis, train_inverse_cov)
             K = p0["pis"].shape[1]
             self.musX_init = blk.gen_domain_grid(kpd, d)
+        if radial_as:
+            # smoe.py:429-434,714-719: ONE steering value per kernel, A_init[:, 0, 0], tiled over the diagonal; A_corr is
+            # not trainable.  The engine keeps A_diagonal (B,K,d,d) with equal diagonal entries and ties their gradient.
+            a0 = p0["A_diagonal"][:, :, 0, 0]
+            p0["A_diagonal"] = np.ascontiguousarray(a0[..., None, None] * np.eye(d, dtype=np.float32))
         self.kernels = K
         # use_diff_center (smoe.py:390-394,746-747): the trained variable is the OFFSET from the kernel
         # grid (initialised to zero); the engine works on grid + offset, the getters subtract the grid.
@@ -248,7 +258,8 @@ class Smoe:
             start_pis=self.kernels, only_y_gamma=bool(self.only_y_gamma), ssim_opt=bool(self.ssim_opt),
             quantization_mode=int(self.quantization_mode), quantize_pis=bool(self.quantize_pis),
             bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
-            upper_bounds=tuple(self.upper_bounds), train_inverse_cov=bool(self.train_inverse_cov))
+            upper_bounds=tuple(self.upper_bounds), train_inverse_cov=bool(self.train_inverse_cov),
+            radial_as=bool(self.radial_as))
         key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
         key = repr(key)
         if key != self._engine_key:
@@ -451,6 +462,8 @@ class Smoe:
         out = {k: v.cpu().numpy().copy() for k, v in p.items()}
         if self._mus_grid is not None:                     # use_diff_center: report the trained offsets
             out["musX"] = out["musX"] - self._mus_grid
+        if self.radial_as:                                 # the reference's variable is (K,) per model
+            out["A_diagonal"] = np.ascontiguousarray(out["A_diagonal"][:, :, 0, 0])
         return {k: sdist.allgather_blocks(v, self.num_blocks) for k, v in out.items()}
 
     def get_params(self):

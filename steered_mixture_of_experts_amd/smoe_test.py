@@ -91,7 +91,7 @@ def build_parser():
 def main(args):
     if len(args.bit_depths) != 5:
         raise ValueError("Number of bit depths must be five!")                        # smoe_test.py:24-25
-    inactive = {"inc_steps": 0, "radial_as": False, "sampling_percentage": 100,
+    inactive = {"inc_steps": 0, "sampling_percentage": 100,
                 "svreg": 0, "hpc_mode": False, "kernel_count_norm_l1": False,
                 "train_svs": False, "train_trafo": False,
                 "only_rec_from_checkpoint": False, "checkpoint_path": None}
@@ -123,10 +123,11 @@ def main(args):
         smoe = Smoe(orig, kpd, use_diff_center=args.use_diff_center, quantization_mode=args.quantization_mode,
                     bit_depths=args.bit_depths, quantize_pis=args.quantize_pis,
                     lower_bounds=args.lower_bounds, upper_bounds=args.upper_bounds, only_y_gamma=only_y_gamma,
-                    loss_mask=loss_mask, ssim_opt=args.ssim_opt, train_inverse_cov=args.train_inverse_cov, **common)
+                    loss_mask=loss_mask, ssim_opt=args.ssim_opt, train_inverse_cov=args.train_inverse_cov,
+                    radial_as=args.radial_as, **common)
     else:
-        if loss_mask is not None or args.ssim_opt or args.train_inverse_cov:
-            raise NotImplementedError("--mode shared: loss masks / SSIM / train_inverse_cov are not built")
+        if loss_mask is not None or args.ssim_opt or args.train_inverse_cov or args.radial_as:
+            raise NotImplementedError("--mode shared: loss masks / SSIM / train_inverse_cov / radial_as are not built")
         smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, only_y_gamma=only_y_gamma,
                           use_diff_center=args.use_diff_center, quantization_mode=args.quantization_mode,
                           quantize_pis=args.quantize_pis, bit_depths=args.bit_depths, lower_bounds=args.lower_bounds,

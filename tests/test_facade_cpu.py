@@ -108,7 +108,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
-    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True},
+    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True, "quantization_mode": 1},
                {"quantization_mode": 3, "use_diff_center": True},
                {"quantization_mode": 2, "ssim_opt": True}):
         with pytest.raises(NotImplementedError):
@@ -439,3 +439,31 @@ def test_constructor_default_is_the_references_inverse_covariance_form():
     q.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
     q.train(2, val_iter=1)                                   # the default form composes with the SSIM loss
     assert 0 < q.get_losses()[-1][1] < 1
+
+
+@pytest.mark.parametrize("ic", [False, True])
+def test_radial_steering_through_the_facade(ic):
+    """radial_as: get_params() returns the reference's (K,) steering variable per block, the fit follows oracle.fit with
+    tied diagonals, A_corr stays untouched."""
+    img = _image(32, 32, seed=13)
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, radial_as=True, train_inverse_cov=ic,
+             engine_factory=OracleEngine)
+    a0 = 36.0 if ic else 6.0
+    assert s.get_params()["A_diagonal"].shape == (4, 4) and np.allclose(s.get_params()["A_diagonal"], a0)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    s.train(6, val_iter=3, u_l1=0.002)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4, lr_steer=0.05, radial_as=True, train_inverse_cov=ic,
+                         u_l1=0.002)
+    p0 = o.init_params(tb, [2, 2])
+    if ic:
+        p0["A_diagonal"] = p0["A_diagonal"] ** 2
+    pn, _, _ = o.fit(p0, tb.reshape(4, -1, 1), o.block_coords((16, 16)), cfg, 6, val_iter=3, dtype=np.float32)
+    got = s.get_params()
+    assert np.allclose(got["A_diagonal"], pn["A_diagonal"][:, :, 0, 0], rtol=1e-5) and not got["A_corr"].any()
+    assert np.abs(got["A_diagonal"] - a0).max() > 0.01
+    for k in ("nu_e", "musX", "pis"):
+        assert np.allclose(got[k], pn[k], rtol=1e-5, atol=2e-6), k
+    r = Smoe(img, init_params=got, batch_size=[16, 16], use_determinant=True, radial_as=True, train_inverse_cov=ic,
+             engine_factory=OracleEngine)                    # the (K,) layout round-trips through init_params
+    assert np.array_equal(r.get_reconstruction(), s.get_reconstruction())

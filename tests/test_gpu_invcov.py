@@ -159,3 +159,47 @@ def test_invcov_facade_and_refused_combinations():
             err = np.abs(m[name][clean] / 0.1 - g_ref).max() / (np.abs(g_ref).max() + 1e-30)
             assert err < 1e-4, (kw, name, err)
         eng.close()
+
+
+@pytest.mark.parametrize("ic", [False, True])
+@pytest.mark.parametrize("shape,C,kpd,yuv,tiling", [((16, 16), 1, [2, 2], False, 16), ((16, 16), 3, [2, 2], True, 64),
+                                                     ((16, 16, 4), 3, [2, 2, 1], True, 64), ((7, 5), 1, [2, 2], False, 16)])
+def test_radial_steering(shape, C, kpd, yuv, tiling, ic):
+    """radial_as (smoe.py:714-719): equal steering diagonals, their gradient is the trace of dL/dA, A_corr is not
+    trained, the u_l1 term counts d times."""
+    B, d = 19, len(shape)
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 900 + C, pis_l1=0.05, u_l1=0.002, radial_as=True,
+                                    train_inverse_cov=ic)
+    a = np.abs(p["A_diagonal"][:, :, 0, 0]) ** (2 if ic else 1)
+    p["A_diagonal"] = (a[..., None, None] * np.eye(d)).astype(np.float32)
+    p["A_corr"] = np.zeros_like(p["A_corr"])
+    active = np.ones((B, K), bool)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.05, u_l1=0.002, radial_as=True, train_inverse_cov=ic)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    recon = np.transpose(eng.forward(T, dp, act, want_recon=True, update_active=False)["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float64, want_grads=True, q_override=recon)
+    st = eng.new_adam_state(dp)
+    eng.fit(T, dp, st, act, 3)
+    torch.cuda.synchronize()
+    got = _to_host(dp)
+    dg = np.diagonal(got["A_diagonal"], axis1=-2, axis2=-1)
+    assert np.all(dg == dg[..., :1]) and not got["A_corr"].any()          # tied, A_corr untouched
+    assert np.abs(dg - np.diagonal(p["A_diagonal"], axis1=-2, axis2=-1)).max() > 0.5        # and really trained (lr 1.0)
+    # first-step gradient through a fresh one-step run
+    dp1 = _to_dev(p)
+    st1 = eng.new_adam_state(dp1)
+    eng.fit(T, dp1, st1, act, 1)
+    torch.cuda.synchronize()
+    tie = (np.abs(ref["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    edge = ((np.abs(ref["y"]) < 1e-6) | (np.abs(ref["y"] - 1) < 1e-6)).any(axis=(1, 2))
+    clean = ~(tie | edge)
+    m = _to_host(st1.m)
+    for name in ("A_diagonal", "musX", "nu_e", "pis"):
+        g_ref = ref["grads"][name][clean]
+        err = np.abs(m[name][clean] / 0.1 - g_ref).max() / (np.abs(g_ref).max() + 1e-30)
+        assert err < 5e-5, (name, err)
+    assert not m["A_corr"].any()
+    eng.close()

@@ -141,7 +141,7 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
                    pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None,
                    quantization_mode=0, quantize_pis=False, bit_depths=(20, 18, 6, 10, 10),
                    lower_bounds=(-2500, -.3, -5, 0, -32), upper_bounds=(2500, 1.3, 5, 2, 32), train_musx=True,
-                   train_inverse_cov=False):
+                   train_inverse_cov=False, radial_as=False):
     """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
     with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
     Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
@@ -156,6 +156,8 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
     N = coords.shape[0]
     dt = coords.dtype
     # smoe.py:732-733  band_part(A_diagonal,0,0) + band_part(set_diag(A_corr,0),-1,0)
+    if radial_as:                                                                # smoe.py:714-719: A_diagonal is (K,)
+        Ad_v = Ad_v.reshape(-1, 1, 1).repeat(1, d, d)
     A = torch.diag_embed(torch.diagonal(Ad_v, dim1=-2, dim2=-1)) + torch.tril(Ac_v, diagonal=-1)
     if train_inverse_cov:                                                        # smoe.py:734-735
         A = A + torch.tril(Ac_v, diagonal=-1).transpose(-1, -2)
