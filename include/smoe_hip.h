@@ -90,6 +90,7 @@ typedef struct smoe_config {
     int32_t radial_as;          /* one steering value per kernel (A = a I): the caller keeps A_diagonal [B,K,d,d] with equal
                                    diagonal entries (and equal Adam slots); their gradient is the trace of dL/dA, A_corr
                                    is not trained                                    smoe.py:349-365,429-434,714-719 */
+    int32_t kernel_count_as_norm_l1; /* pis_l1 * sum(pis) / count(qpis > 0) instead of / start_pis     smoe.py:1022-1027 */
 } smoe_config;
 
 /* Parameter set in the reference's get_params() layout (smoe.py:1795-1800) with a

@@ -49,6 +49,8 @@ def _cfg(cfg):
     c.grad_clip = cfg.grad_clip or 0.0
     c.pis_l1, c.u_l1, c.start_pis = cfg.pis_l1, cfg.u_l1, cfg.k0
     c.only_y_gamma = int(getattr(cfg, 'only_y_gamma', False))
+    if getattr(cfg, "kernel_count_as_norm_l1", False):
+        raise NotImplementedError("kernel_count_as_norm_l1 lives in smoe_oracle.py")
     if getattr(cfg, "radial_as", False):
         raise NotImplementedError("the plain-C restatement has the CLI-default form only; radial_as lives in smoe_oracle.py")
     if getattr(cfg, "train_inverse_cov", False):

@@ -72,6 +72,7 @@ class OracleConfig:
     # fake-quantised parameters inside the graph (smoe.py:474-538); order of the 5-tuples: A, musX, nu_e, pis, gamma_e
     train_inverse_cov: bool = False       # smoe.py:734-735,791-793: A symmetric, maha = r^T A r (the ctor default is
                                           # True, the CLI default False, smoe_test.py:342)
+    kernel_count_as_norm_l1: bool = False  # smoe.py:1022-1027: the pis l1 term is normalised by count(qpis > 0), not start_pis
     radial_as: bool = False               # smoe.py:349-365,429-434,714-719: ONE steering value per kernel (A = a I),
                                           # A_corr not trainable.  Held here as A_diagonal with equal diagonal entries
     quantization_mode: int = 0            # 0/1: none in the graph; 2: fixed ranges; 3: min/max of the model's kernels
@@ -491,7 +492,9 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
         ssim_c, dssim = ssim_and_grad(q, t, cfg.block_shape, T, want_grad=want_grads)
         loss_pixel = T(1) - np.sum(ssim_c * sw[None, :], axis=1)
     diagA = np.diagonal(A, axis1=-2, axis2=-1)               # (B,K,d)
-    reg_pi = T(cfg.pis_l1) * np.sum(np.where(act, pis, T(0)), axis=1) / T(cfg.k0)     # smoe.py:1027
+    # smoe.py:1012,1022-1027: num_pi_op = count_nonzero(pis_mask) (independent of the kernel list; no gradient)
+    k0 = np.maximum(np.sum(pis > 0, axis=1), 1).astype(T) if cfg.kernel_count_as_norm_l1 else np.full((B,), cfg.k0, dtype=T)
+    reg_pi = T(cfg.pis_l1) * np.sum(np.where(act, pis, T(0)), axis=1) / k0             # smoe.py:1027
     reg_u = T(cfg.u_l1) * np.sum(np.where(act[:, :, None], diagA, T(0)), axis=(1, 2))  # smoe.py:1044
     loss = loss_pixel + reg_pi + reg_u                       # smoe.py:1051
 
@@ -517,7 +520,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     u = np.where(passS, w * (h - dotp[:, None, :]), h * w)   # dL/dlog g  (if floored: dL/dg*g = h*g/S)
     u = np.where(act[:, :, None], u, T(0))
     safe_pi = np.where(act, pis, T(1))
-    g_pi = np.where(act, np.sum(u, axis=2) / safe_pi + T(cfg.pis_l1) / T(cfg.k0), T(0))
+    g_pi = np.where(act, np.sum(u, axis=2) / safe_pi + T(cfg.pis_l1) / k0[:, None], T(0))
     # steering: dm/dA[l,m] = 2 r_l z_m, dL/dm = -u/2
     if ic:      # maha = r^T A r: dm/dA_ll = r_l^2, dm/dA_corr[l,m] = 2 r_l r_m (the entry sits at (l,m) and (m,l))
         rr = np.einsum("bkn,bknl,bknm->bklm", u, r, r)

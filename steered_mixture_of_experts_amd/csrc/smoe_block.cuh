@@ -270,6 +270,16 @@ struct BlockRanges {
     }
 };
 
+// kernel_count_as_norm_l1 (smoe.py:1012,1022-1023): number of kernels with (q)pis > 0, at least 1; P already quantised
+template <int D, int C, int K>
+__device__ __forceinline__ float count_pis(const float* P) {
+    using Lt = Layout<D, C, K>;
+    float cnt = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) cnt += (P[k * Lt::PK + Lt::O_PI] > 0.0f) ? 1.0f : 0.0f;
+    return fmaxf(cnt, 1.0f);
+}
+
 // Replace the packed parameters P by the fake-quantised values the graph is built on.
 // FULL = false: only the pis (quantize_pis, the reference CLI default) -- a few instructions, kept as a
 // run-time branch in the default kernels; modes 2 / 3 live in their own instantiations (QUANT) so that their
@@ -1212,10 +1222,11 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             R.template derive<IC>(kc);
             frozen = R.frozen();
             if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
+                const float rp = kc.kcount_norm ? kc.pis_l1_raw / count_pis<D, C, K>(R.P) : reg_pi;   // smoe.py:1022-1023
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (R.act(k)) {
-                        reg_loss += reg_pi * R.pi(k);
+                        reg_loss += rp * R.pi(k);
 #pragma unroll
                         for (int l = 0; l < D; ++l) reg_loss += reg_u * R.A(k, l, l);
                     }
@@ -1294,7 +1305,18 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 float piv = s_par[k * Lt::PK + Lt::O_PI];
                 if (kc.qpis) piv = fq_val(piv, fq_fixed(kc, 3));
                 const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (piv > 0.0f);
-                gsum += act ? reg[s] : 0.0f;
+                float rs = reg[s];
+                if (kc.kcount_norm && (jc - k * Lt::PK) == Lt::O_PI) {          // pis_l1 / count(qpis > 0), smoe.py:1022-1027
+                    float cnt = 0.0f;
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) {
+                        float pk = s_par[kk * Lt::PK + Lt::O_PI];
+                        if (kc.qpis) pk = fq_val(pk, fq_fixed(kc, 3));
+                        cnt += (pk > 0.0f) ? 1.0f : 0.0f;
+                    }
+                    rs = kc.pis_l1_raw / fmaxf(cnt, 1.0f);
+                }
+                gsum += act ? rs : 0.0f;
             }
             gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;     // fixed-range fake quant: straight-through inside
             if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
@@ -1495,11 +1517,12 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             if (j == Lt::S_LOSS) {
                 float lossv = SSIM ? 1.0f + total[s] : total[s];
                 if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
+                    const float rp = a.kc.kcount_norm ? a.kc.pis_l1_raw / count_pis<D, C, K>(R.P) : a.reg_pi;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const bool act = R.act(k);
                         if (act) {
-                            lossv += a.reg_pi * R.pi(k);
+                            lossv += rp * R.pi(k);
 #pragma unroll
                             for (int l = 0; l < D; ++l) lossv += a.reg_u * R.A(k, l, l);
                         }

@@ -281,6 +281,8 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
                       cfg->lower_bounds, cfg->upper_bounds);
     kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;
     kc.radial = cfg->radial_as ? 1 : 0;
+    kc.kcount_norm = cfg->kernel_count_as_norm_l1 ? 1 : 0;
+    kc.pis_l1_raw = cfg->pis_l1;
     if (cfg->ssim_opt && !find_variant(h, 1, false)) {
         smoe_destroy(h);
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt planes of this block size do not fit in LDS");
@@ -605,6 +607,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
                       cfg->lower_bounds, cfg->upper_bounds);
     kc.inverse_cov = 0;                       // train_inverse_cov / radial_as are not built for the shared-kernel mode
     kc.radial = 0;
+    kc.kcount_norm = 0;
+    kc.pis_l1_raw = cfg->pis_l1;
     *out = h;
     return SMOE_OK;
 }

@@ -33,6 +33,8 @@ struct KernelConsts {
     float q_levels[5];  // 2^bits - 1
     int inverse_cov;    // train_inverse_cov (smoe.py:734-735,791-793): A symmetric, maha = r^T A r
     int radial;         // radial_as (smoe.py:714-719): the steering diagonal is one value per kernel
+    int kcount_norm;    // kernel_count_as_norm_l1: pis l1 term normalised by count(qpis > 0) (smoe.py:1022-1027)
+    float pis_l1_raw;   // the un-normalised pis_l1 for that
 };
 
 struct FitArgs {

@@ -50,6 +50,7 @@ class EngineConfig:
     upper_bounds: Sequence[float] = (2500, 1.3, 5, 2, 32)
     train_inverse_cov: bool = False      # smoe.py:734-735,791-793 (reference ctor default True, CLI default False)
     radial_as: bool = False              # smoe.py:714-719: equal steering diagonals, tied gradient, A_corr untrained
+    kernel_count_as_norm_l1: bool = False  # smoe.py:1022-1027
 
     @property
     def dim(self) -> int:
@@ -120,6 +121,7 @@ class BlockEngine:
             c.lower_bounds[i], c.upper_bounds[i] = float(cfg.lower_bounds[i]), float(cfg.upper_bounds[i])
         c.train_inverse_cov = int(cfg.train_inverse_cov)
         c.radial_as = int(cfg.radial_as)
+        c.kernel_count_as_norm_l1 = int(cfg.kernel_count_as_norm_l1)
         self._c = c
         self._h = C.c_void_p()
         _lib.check(self.lib.smoe_create(C.byref(self._h), C.byref(c)))

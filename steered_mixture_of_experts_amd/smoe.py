@@ -72,7 +72,6 @@ class Smoe:
         unsupported = {
 
             "train_svs": train_svs, "train_trafo": train_trafo,
-            "kernel_count_as_norm_l1": kernel_count_as_norm_l1,
         }
         for name, val in unsupported.items():
             if val:
@@ -106,6 +105,7 @@ class Smoe:
         self.ssim_opt = ssim_opt
         self.use_diff_center = use_diff_center
         self.radial_as = radial_as
+        self.kernel_count_as_norm_l1 = bool(kernel_count_as_norm_l1)
         self.use_determinant = use_determinant
         self.quantization_mode = quantization_mode
         self.quantize_pis = bool(quantize_pis) or quantization_mode >= 2               # smoe_test.py:36-37, smoe.py:474
@@ -259,7 +259,7 @@ class Smoe:
             quantization_mode=int(self.quantization_mode), quantize_pis=bool(self.quantize_pis),
             bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
             upper_bounds=tuple(self.upper_bounds), train_inverse_cov=bool(self.train_inverse_cov),
-            radial_as=bool(self.radial_as))
+            radial_as=bool(self.radial_as), kernel_count_as_norm_l1=self.kernel_count_as_norm_l1)
         key = tuple(sorted(cfg.__dict__.items(), key=lambda kv: kv[0]))
         key = repr(key)
         if key != self._engine_key:

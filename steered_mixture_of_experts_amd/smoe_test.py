@@ -92,7 +92,7 @@ def main(args):
     if len(args.bit_depths) != 5:
         raise ValueError("Number of bit depths must be five!")                        # smoe_test.py:24-25
     inactive = {"inc_steps": 0, "sampling_percentage": 100,
-                "svreg": 0, "hpc_mode": False, "kernel_count_norm_l1": False,
+                "svreg": 0, "hpc_mode": False,
                 "train_svs": False, "train_trafo": False,
                 "only_rec_from_checkpoint": False, "checkpoint_path": None}
     for name, val in inactive.items():
@@ -124,9 +124,9 @@ def main(args):
                     bit_depths=args.bit_depths, quantize_pis=args.quantize_pis,
                     lower_bounds=args.lower_bounds, upper_bounds=args.upper_bounds, only_y_gamma=only_y_gamma,
                     loss_mask=loss_mask, ssim_opt=args.ssim_opt, train_inverse_cov=args.train_inverse_cov,
-                    radial_as=args.radial_as, **common)
+                    radial_as=args.radial_as, kernel_count_as_norm_l1=args.kernel_count_norm_l1, **common)
     else:
-        if loss_mask is not None or args.ssim_opt or args.train_inverse_cov or args.radial_as:
+        if loss_mask is not None or args.ssim_opt or args.train_inverse_cov or args.radial_as or args.kernel_count_norm_l1:
             raise NotImplementedError("--mode shared: loss masks / SSIM / train_inverse_cov / radial_as are not built")
         smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, only_y_gamma=only_y_gamma,
                           use_diff_center=args.use_diff_center, quantization_mode=args.quantization_mode,

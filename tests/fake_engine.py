@@ -40,14 +40,14 @@ class OracleEngine:
             adam_eps=cfg.adam_eps, grad_clip=(cfg.grad_clip or None), pis_l1=cfg.pis_l1, u_l1=cfg.u_l1,
             start_pis=cfg.start_pis or cfg.kernels, only_y_gamma=getattr(cfg, 'only_y_gamma', False),
             ssim_opt=getattr(cfg, 'ssim_opt', False), train_inverse_cov=getattr(cfg, 'train_inverse_cov', False),
-            radial_as=getattr(cfg, 'radial_as', False),
+            radial_as=getattr(cfg, 'radial_as', False), kernel_count_as_norm_l1=getattr(cfg, 'kernel_count_as_norm_l1', False),
             quantization_mode=getattr(cfg, 'quantization_mode', 0),
             quantize_pis=getattr(cfg, 'quantize_pis', False), bit_depths=tuple(getattr(cfg, 'bit_depths', (20, 18, 6, 10, 10))),
             lower_bounds=tuple(getattr(cfg, 'lower_bounds', (-2500, -.3, -5, 0, -32))),
             upper_bounds=tuple(getattr(cfg, 'upper_bounds', (2500, 1.3, 5, 2, 32))))
         # what the plain-C restatement lacks
         self.numpy_only = (self.ocfg.ssim_opt or self.ocfg.quantization_mode >= 2 or self.ocfg.train_inverse_cov
-                           or self.ocfg.radial_as)
+                           or self.ocfg.radial_as or self.ocfg.kernel_count_as_norm_l1)
         self.coords = np.ascontiguousarray(o.block_coords(cfg.block_shape).T)
 
     def close(self):

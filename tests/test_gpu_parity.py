@@ -410,3 +410,35 @@ def test_only_y_gamma(tiling):
     after = dp["gamma_e"].cpu().numpy()
     assert np.array_equal(after[..., 1:], before[..., 1:]) and not np.array_equal(after[..., 0], before[..., 0])
     eng.close()
+
+
+@pytest.mark.parametrize("qpis", [False, True])
+def test_kernel_count_as_norm_l1(qpis):
+    """kernel_count_as_norm_l1 (smoe.py:1022-1027): the pis l1 term is normalised by the number of kernels with
+    (q)pis > 0 -- independent of the kernel list -- instead of start_pis."""
+    shape, C, kpd = (16, 16), 1, [2, 4]
+    B = 24
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 55, pis_l1=0.3, u_l1=0.002, kernel_count_as_norm_l1=True,
+                                    quantize_pis=qpis)
+    p["pis"][0, 1] = 0.0
+    p["pis"][0, 5] = -0.2
+    p["pis"][1, 2] = 0.0006 if qpis else 0.0           # rounds to 0 on the pis lattice
+    active = np.ones((B, K), bool)
+    active[0, 0] = False
+    eng = _engine(shape, C, K, pis_l1=0.3, u_l1=0.002, kernel_count_as_norm_l1=True, quantize_pis=qpis)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True, q_override=recon)
+    plain = o.forward(p, tgt, coords, active, o.OracleConfig(**{**cfg.__dict__, "kernel_count_as_norm_l1": False}), None,
+                      np.float32, q_override=recon)
+    assert _close(fw["loss"].cpu().numpy(), ref["loss"], rtol=2e-5).all()
+    assert np.abs(ref["loss"] - plain["loss"])[:2].min() > 1e-3          # blocks 0 and 1 lost kernels: different norm
+    st = eng.new_adam_state(dp)
+    eng.fit(T, dp, st, act, 1)
+    torch.cuda.synchronize()
+    g = st.m["pis"].cpu().numpy() / 0.1
+    assert np.abs(g - ref["grads"]["pis"]).max() < 2e-5 * np.abs(ref["grads"]["pis"]).max()
+    eng.close()

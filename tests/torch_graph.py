@@ -141,7 +141,7 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
                    pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None,
                    quantization_mode=0, quantize_pis=False, bit_depths=(20, 18, 6, 10, 10),
                    lower_bounds=(-2500, -.3, -5, 0, -32), upper_bounds=(2500, 1.3, 5, 2, 32), train_musx=True,
-                   train_inverse_cov=False, radial_as=False):
+                   train_inverse_cov=False, radial_as=False, kernel_count_as_norm_l1=False):
     """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
     with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
     Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
@@ -215,6 +215,8 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
             ssim = torch.mean(ssim_per_channel)
         loss_pixel = 1 - ssim
     k0 = K if start_pis is None else start_pis
+    if kernel_count_as_norm_l1:                                                  # smoe.py:1012,1022-1023
+        k0 = float(torch.count_nonzero(pis_mask))
     loss = loss_pixel + pis_l1 * pis.sum() / k0 + u_l1 * torch.diagonal(A, dim1=-2, dim2=-1).sum()
     return {"loss": loss, "mse_op": mse * (2 ** precision) ** 2, "res": res, "pre": pre,
             "w_e": w_e, "indices": indices[klb], "bool_mask": bool_mask}
