@@ -233,13 +233,9 @@ class Smoe:
         self.best_mse = []
         self.iter = iter_offset
         self.valid = False
-        self.reconstruction_image = None
-        self.weight_matrix_argmax = None
-        self.weight_matrix = None
+        self._images = None                  # reconstruction_image / weight_matrix_argmax / weight_matrix (lazy, see _stitch)
         self.qvalid = False
-        self.qreconstruction_image = None
-        self.qweight_matrix_argmax = None
-        self.qweight_matrix = None
+        self._qimages = None                 # their with_quantized_params counterparts
         self.best_qloss = None
         self.best_qmse = []
 
@@ -325,12 +321,7 @@ class Smoe:
                               want_recon=update_reconstruction, want_argmax=update_reconstruction,
                               want_gate=update_reconstruction, update_active=False)
             if update_reconstruction:
-                keep = (self.reconstruction_image, self.weight_matrix_argmax, self.weight_matrix, self.valid)
-                self._stitch(out)
-                self.qreconstruction_image, self.qweight_matrix_argmax, self.qweight_matrix = \
-                    self.reconstruction_image, self.weight_matrix_argmax, self.weight_matrix
-                self.reconstruction_image, self.weight_matrix_argmax, self.weight_matrix, self.valid = keep
-                self.qvalid = True
+                self._stitch(out, quantised=True)
             loss_val, mse_val, num_pi = self._global(out["loss"], out["sse"])
             return loss_val, mse_val, num_pi, 0
         if train:
@@ -350,19 +341,48 @@ class Smoe:
         self._last_block_loss = loss
         return loss_val, mse_val, num_pi, 0
 
-    def _stitch(self, out):
-        """Assemble the full-image reconstruction / argmax / gate arrays (smoe.py:1719-1783)."""
+    def _assemble(self, out):
+        """Full-image reconstruction / argmax / gate arrays from one pass's device outputs (smoe.py:1719-1783)."""
         bs, d = self.batch_size_valued, self.dim_domain
         recon = blk.from_planar(out["recon"].cpu().numpy(), bs)                       # (B,*bs,C)
         recon = sdist.allgather_blocks(recon, self.num_blocks)
-        self.reconstruction_image = blk.blocks_to_image(recon, self.image.shape[:d], bs)
+        image = blk.blocks_to_image(recon, self.image.shape[:d], bs)
         am = out["argmax"].cpu().numpy().astype(np.int64).reshape((self.B,) + bs)
         am = am + (np.arange(self.lo, self.hi, dtype=np.int64) * self.kernels).reshape((-1,) + (1,) * d)
         am = sdist.allgather_blocks(am, self.num_blocks)
-        self.weight_matrix_argmax = blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
+        argmax = blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
         gate = out["gate_w"].cpu().numpy().reshape((self.B, self.kernels) + bs)
-        self.weight_matrix = sdist.allgather_blocks(gate, self.num_blocks)            # (B,K,*bs)
-        self.valid = True
+        return image, argmax, sdist.allgather_blocks(gate, self.num_blocks)            # gate: (B,K,*bs)
+
+    def _stitch(self, out, quantised=False):
+        """Keep the products of an update_reconstruction pass.  Single process: the device tensors are kept and the
+        host copy + stitching (tens of ms for large images) happens when an attribute / getter asks; several ranks:
+        assembled right away, because the gather is a collective every rank takes part in."""
+        slot = "_qimages" if quantised else "_images"
+        if self.world_size == 1:
+            setattr(self, slot, {"pending": out})
+        else:
+            setattr(self, slot, dict(zip(("image", "argmax", "gate"), self._assemble(out))))
+        if quantised:
+            self.qvalid = True
+        else:
+            self.valid = True
+
+    def _image_product(self, slot, name):
+        st = getattr(self, slot)
+        if st is None:
+            return None
+        if "pending" in st:
+            st = dict(zip(("image", "argmax", "gate"), self._assemble(st["pending"])))
+            setattr(self, slot, st)
+        return st[name]
+
+    reconstruction_image = property(lambda self: self._image_product("_images", "image"))
+    weight_matrix_argmax = property(lambda self: self._image_product("_images", "argmax"))
+    weight_matrix = property(lambda self: self._image_product("_images", "gate"))
+    qreconstruction_image = property(lambda self: self._image_product("_qimages", "image"))
+    qweight_matrix_argmax = property(lambda self: self._image_product("_qimages", "argmax"))
+    qweight_matrix = property(lambda self: self._image_product("_qimages", "gate"))
 
     # -- training loop (smoe.py:1485-1603) -------------------------------------------------
     def train(self, num_iter, val_iter=100, ukl_iter=None, optimizer1=None, optimizer2=None, optimizer3=None,
