@@ -212,6 +212,7 @@ typedef struct smoe_shared_config {
     int32_t bit_depths[5];
     float   lower_bounds[5];
     float   upper_bounds[5];
+    int32_t ssim_opt;                   /* loss_pixel = 1 - SSIM of every batch (2-d, >= 5 pixels per axis)  smoe.py:980-1011 */
 } smoe_shared_config;
 
 typedef struct smoe_shared_context* smoe_shared_handle;

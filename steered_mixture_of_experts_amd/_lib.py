@@ -56,7 +56,7 @@ class SmoeSharedConfig(C.Structure):
         ("grad_clip", C.c_float), ("pis_l1", C.c_float), ("u_l1", C.c_float), ("start_pis", C.c_int32),
         ("only_y_gamma", C.c_int32), ("overlap", C.c_int32),
         ("quantization_mode", C.c_int32), ("quantize_pis", C.c_int32), ("bit_depths", C.c_int32 * 5),
-        ("lower_bounds", C.c_float * 5), ("upper_bounds", C.c_float * 5),
+        ("lower_bounds", C.c_float * 5), ("upper_bounds", C.c_float * 5), ("ssim_opt", C.c_int32),
     ]
 
 

@@ -20,19 +20,13 @@
 #include <stdint.h>
 
 #include "smoe_device.h"
+#include "smoe_ssim.cuh"
 
 namespace smoe {
 
 // ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {
-    // LDS hand-off between lanes of ONE wavefront: DS ops of a wave execute in order,
-    // so only compiler ordering + completion of the stores is required.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // A value that is the same in every lane of the wavefront -> scalar register.
@@ -788,171 +782,6 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
         }
         wave_lds_sync();
     }
-}
-
-// ---------------------------------------------------------------------------
-// SSIM loss stage (ssim_opt; smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d blocks.
-// One wavefront works on one block-channel plane held in LDS.  The reference pads the block SYMMETRIC
-// by 5 (smoe.py:993-996) and correlates with the 11x11 Gaussian (sigma 1.5, VALID): per axis that is
-// the b x b matrix  T[i][j] = sum_a g[a] * [mirror(i + a - 5) == j]  (symmetric, band |i - j| <= 5,
-// built on the host), so the window statistic is  Tr * plane * Tc  and its adjoint is the same
-// product on the coefficient maps -- no padded copy, no scatter.
-// ---------------------------------------------------------------------------
-constexpr float SSIM_C1 = 0.0001f;    // (0.01 * max_val)^2   image_ops_impl.py:74,110
-constexpr float SSIM_C2 = 0.0009f;    // (0.03 * max_val)^2   image_ops_impl.py:75,111
-
-// Walk of the outputs n = lane, lane + 64, ... of one plane as (row i, column j) without a division per step.
-struct SsimWalk {
-    int i, j, di, dj;      // current position; per-step increments 64 / bw and 64 % bw
-    __device__ __forceinline__ SsimWalk(int lane, int bw) : i(lane / bw), j(lane - (lane / bw) * bw), di(64 / bw), dj(64 % bw) {}
-    __device__ __forceinline__ void next(int bw) {
-        j += dj; i += di;
-        if (j >= bw) { j -= bw; i += 1; }
-    }
-};
-
-__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
-
-// Tap tables are banded: Tb[i][a] = T[i][i + a - 5], zero where i + a - 5 leaves the axis, so a tap is
-// weight * plane[clamp(i + a - 5)] with no compare / select.
-// dst[p][i][j] = sum_r Tr[i][r] * f_p(r, j): window sums along axis 0 of x, x^2, x*y, y, y^2
-__device__ __forceinline__ void ssim_cols_products(float* __restrict__ dst, const float* __restrict__ xp,
-                                                   const float* __restrict__ yp, const float* __restrict__ Trb,
-                                                   int bh, int bw, int N, int lane) {
-    SsimWalk w(lane, bw);
-    for (int n = lane; n < N; n += 64, w.next(bw)) {
-        const float* tw = Trb + w.i * 11;
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, s4 = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 11; ++a) {
-            const int o = clampi(w.i + a - 5, bh - 1) * bw + w.j;
-            const float wt = tw[a];
-            const float xv = xp[o], yv = yp[o];
-            const float wx = wt * xv, wy = wt * yv;
-            s0 += wx;
-            s1 = fmaf(wx, xv, s1);
-            s2 = fmaf(wx, yv, s2);
-            s3 += wy;
-            s4 = fmaf(wy, yv, s4);
-        }
-        dst[n] = s0;
-        dst[N + n] = s1;
-        dst[2 * N + n] = s2;
-        dst[3 * N + n] = s3;
-        dst[4 * N + n] = s4;
-    }
-}
-
-// dst[p][i][j] = sum_c Tc[j][c] * src[p][i][c]
-template <int NP>
-__device__ __forceinline__ void ssim_rows(float* __restrict__ dst, const float* __restrict__ src,
-                                          const float* __restrict__ Tcb, int bw, int N, int lane) {
-    SsimWalk w(lane, bw);
-    for (int n = lane; n < N; n += 64, w.next(bw)) {
-        const float* tw = Tcb + w.j * 11;
-        const int row = w.i * bw;
-        float s[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) s[p] = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 11; ++a) {
-            const int o = row + clampi(w.j + a - 5, bw - 1);
-            const float wt = tw[a];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) s[p] = fmaf(wt, src[p * N + o], s[p]);
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) dst[p * N + n] = s[p];
-    }
-}
-
-// Row pass of the five sums + the SSIM formula per window position (image_ops_impl.py:110-129).
-// Returns this lane's sum of luminance * contrast-structure; with GRAD the three coefficient maps
-// scale * d(l*cs)/d{mu_x, E[x^2], E[xy]} go to dst.
-template <bool GRAD>
-__device__ __forceinline__ float ssim_rows_stats(float* __restrict__ dst, const float* __restrict__ src,
-                                                 const float* __restrict__ Tcb, int bw, int N, int lane, float scale) {
-    float part = 0.0f;
-    SsimWalk w(lane, bw);
-    for (int n = lane; n < N; n += 64, w.next(bw)) {
-        const float* tw = Tcb + w.j * 11;
-        const int row = w.i * bw;
-        float mx = 0.0f, sx = 0.0f, pxy = 0.0f, my = 0.0f, sy = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 11; ++a) {
-            const int o = row + clampi(w.j + a - 5, bw - 1);
-            const float wt = tw[a];
-            mx = fmaf(wt, src[o], mx);
-            sx = fmaf(wt, src[N + o], sx);
-            pxy = fmaf(wt, src[2 * N + o], pxy);
-            my = fmaf(wt, src[3 * N + o], my);
-            sy = fmaf(wt, src[4 * N + o], sy);
-        }
-        const float num0 = mx * my * 2.0f;
-        const float den0 = mx * mx + my * my;
-        const float N0 = num0 + SSIM_C1, D0 = den0 + SSIM_C1;
-        const float N1 = (pxy * 2.0f - num0) + SSIM_C2;
-        const float D1 = ((sx + sy) - den0) + SSIM_C2;
-        const float r0 = 1.0f / D0, r1 = 1.0f / D1;
-        const float lum = N0 * r0, cs = N1 * r1;
-        part = fmaf(lum, cs, part);
-        if (GRAD) {
-            const float dl = (2.0f * my - lum * (2.0f * mx)) * r0;             // d lum / d mu_x
-            const float dc = (cs * (2.0f * mx) - 2.0f * my) * r1;              // d cs / d mu_x
-            dst[n] = scale * fmaf(cs, dl, lum * dc);
-            dst[N + n] = scale * (-(lum * cs) * r1);                            // d / d E[x^2]
-            dst[2 * N + n] = scale * ((lum + lum) * r1);                        // d / d E[xy]
-        }
-    }
-    return part;
-}
-
-// Column pass of the adjoint + assembly of dL/dq:  g = Ga + 2 x Gb + y Gc, written over x in place.
-__device__ __forceinline__ void ssim_cols_adjoint(float* __restrict__ xp, const float* __restrict__ yp,
-                                                  const float* __restrict__ src, const float* __restrict__ Trb,
-                                                  int bh, int bw, int N, int lane) {
-    SsimWalk w(lane, bw);
-    for (int n = lane; n < N; n += 64, w.next(bw)) {
-        const float* tw = Trb + w.i * 11;
-        float ga = 0.0f, gb = 0.0f, gc = 0.0f;
-#pragma unroll
-        for (int a = 0; a < 11; ++a) {
-            const int o = clampi(w.i + a - 5, bh - 1) * bw + w.j;
-            const float wt = tw[a];
-            ga = fmaf(wt, src[o], ga);
-            gb = fmaf(wt, src[N + o], gb);
-            gc = fmaf(wt, src[2 * N + o], gc);
-        }
-        const float xv = xp[n];
-        xp[n] = fmaf(yp[n], gc, fmaf(xv + xv, gb, ga));
-    }
-}
-
-// 1 - SSIM of one block: returns this lane's share of -sum_c sw_c * mean(l * cs); with GRAD the plane
-// X[c] is replaced by dL/dq.  sw[c] = channel weight / window count (kc.sw).
-template <int C, bool GRAD>
-__device__ __forceinline__ float ssim_block(float* __restrict__ X, const float* __restrict__ tgt,
-                                            float* __restrict__ wa, float* __restrict__ wb,
-                                            const float* __restrict__ Tr, const float* __restrict__ Tc,
-                                            const float* __restrict__ sw, int bh, int bw, int N, int lane) {
-    float part = 0.0f;
-#pragma unroll 1
-    for (int c = 0; c < C; ++c) {
-        float* xp = X + c * N;
-        const float* yp = tgt + c * N;
-        ssim_cols_products(wa, xp, yp, Tr, bh, bw, N, lane);
-        wave_lds_sync();
-        const float swc = (c == 0) ? sw[0] : ((c == 1) ? sw[1] : sw[2]);   // no dynamic indexing of kernel arguments
-        part -= swc * ssim_rows_stats<GRAD>(wb, wa, Tc, bw, N, lane, -swc);
-        if (GRAD) {
-            wave_lds_sync();
-            ssim_rows<3>(wa, wb, Tc, bw, N, lane);
-            wave_lds_sync();
-            ssim_cols_adjoint(xp, yp, wa, Tr, bh, bw, N, lane);
-        }
-        wave_lds_sync();
-    }
-    return part;
 }
 
 // ---------------------------------------------------------------------------

@@ -462,6 +462,7 @@ struct smoe_shared_context {
     float* d_axes;        // concatenated per-axis coordinate tables
     float* d_probes;      // [NB][D][3]
     double* d_racc;       // [K*PK + K]
+    float* d_ssim_T;      // ssim_opt: banded tap tables of the batch shape
     smoe::KernelConsts kc;
 };
 
@@ -477,6 +478,9 @@ void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
         a.image_shape[l] = (l < c.dim) ? c.image_shape[l] : 1;
     }
     a.overlap = c.overlap;
+    a.ssim = c.ssim_opt ? 1 : 0;
+    a.ssim_T = h->d_ssim_T;
+    a.ssim_off = (int)(smoe::shared_lds_bytes(c.dim, c.channels, c.kernels, h->KW) / sizeof(float));
     a.Nb = h->Nb; a.K = c.kernels; a.KW = h->KW;
     a.kc = h->kc;
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
@@ -517,6 +521,11 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_shared_create: ") + qmsg);
         if (cfg->quantization_mode == 3)
             return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: quantization_mode 3 (image-wide min/max ranges) is not built for the shared-kernel mode");
+    }
+    if (cfg->ssim_opt) {
+        if (cfg->dim != 2) return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt is built for 2-d batches only");
+        if (cfg->batch_shape[0] < 5 || cfg->batch_shape[1] < 5)
+            return fail(SMOE_ERR_INVALID, "smoe_shared_create: ssim_opt needs at least 5 pixels per batch axis (SYMMETRIC padding by 5)");
     }
     if (!smoe::shared_supported(cfg->dim, cfg->channels, (int)Nb))
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: batch too large (<= 2048 pixels for 1 channel, <= 1024 for 3)");
@@ -571,17 +580,34 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         }
     }
     const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
-    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr;
+    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr;
+    if (cfg->ssim_opt) {
+        const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
+                            smoe::shared_ssim_lds_bytes(cfg->channels, (int)Nb, cfg->batch_shape[0], cfg->batch_shape[1]);
+        if (need > 160u * 1024u) {
+            delete h;
+            return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt planes of this batch size do not fit in LDS");
+        }
+    }
     hipError_t e = hipMalloc(&h->d_axes, sizeof(float) * axes.size());
     if (e == hipSuccess) e = hipMalloc(&h->d_probes, sizeof(float) * probes.size());
     if (e == hipSuccess) e = hipMalloc(&h->d_racc, sizeof(double) * nacc);
     if (e == hipSuccess) e = hipMemcpy(h->d_axes, axes.data(), sizeof(float) * axes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * probes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(h->d_racc, 0, sizeof(double) * nacc);
+    if (e == hipSuccess && cfg->ssim_opt) {
+        const int bh = cfg->batch_shape[0], bw = cfg->batch_shape[1];
+        std::vector<float> tabs((size_t)11 * (bh + bw));
+        ssim_axis_table(bh, tabs.data());
+        ssim_axis_table(bw, tabs.data() + (size_t)11 * bh);
+        e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
+        if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (h->d_axes) (void)hipFree(h->d_axes);
         if (h->d_probes) (void)hipFree(h->d_probes);
         if (h->d_racc) (void)hipFree(h->d_racc);
+        if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
         delete h;
         return fail_hip(e, "smoe_shared_create: workspace");
     }
@@ -605,6 +631,11 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     kc.only_y_gamma = (cfg->only_y_gamma && cfg->use_yuv && cfg->train_gammas) ? 1 : 0;
     fill_quant_consts(kc, cfg->quantization_mode, cfg->quantize_pis, cfg->train_musx, cfg->bit_depths,
                       cfg->lower_bounds, cfg->upper_bounds);
+    for (int ch = 0; ch < SMOE_MAX_CHANNELS; ++ch) kc.sw[ch] = 0.0f;
+    for (int ch = 0; ch < C; ++ch) {                   // smoe.py:1006-1009, mean over the Nb window positions of a batch
+        const double w = cfg->use_yuv ? ((ch == 0) ? 6.0 / 8.0 : 1.0 / 8.0) : 1.0 / (double)C;
+        kc.sw[ch] = (float)(w / (double)Nb);
+    }
     kc.inverse_cov = 0;                       // train_inverse_cov / radial_as are not built for the shared-kernel mode
     kc.radial = 0;
     kc.kcount_norm = 0;
@@ -619,6 +650,7 @@ int smoe_shared_destroy(smoe_shared_handle h) {
     if (h->d_axes) (void)hipFree(h->d_axes);
     if (h->d_probes) (void)hipFree(h->d_probes);
     if (h->d_racc) (void)hipFree(h->d_racc);
+    if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
     delete h;
     return SMOE_OK;
 }

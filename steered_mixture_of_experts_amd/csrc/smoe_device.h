@@ -139,6 +139,9 @@ struct SharedArgs {
     int update_lists;
     KernelConsts kc;
     float reg_pi, reg_u;
+    const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
+    int ssim;                 // 1: loss_pixel = 1 - SSIM of the batch
+    int ssim_off;             // float offset of the SSIM planes inside the workgroup's LDS
 };
 
 struct SharedAdamArgs {
@@ -162,6 +165,7 @@ struct SharedReadmitArgs {
 };
 
 size_t shared_lds_bytes(int D, int C, int K, int KW);
+size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw);
 bool shared_supported(int D, int C, int Nb);
 hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st);
 hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st);

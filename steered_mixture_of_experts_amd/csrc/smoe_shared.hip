@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "smoe_device.h"
+#include "smoe_ssim.cuh"
 
 namespace smoe {
 
@@ -68,7 +69,10 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // ---------------------------------------------------------------------------------------------
 // one pass over all batches
 // ---------------------------------------------------------------------------------------------
-template <int D, int C, int PXL, bool TRAIN>
+// SSIM (ssim_opt, 2-d batches): loss_pixel = 1 - SSIM of the batch (smoe.py:980-1011); the quantised reconstruction and
+// the target of the batch go to LDS planes, the whole workgroup runs the SSIM stage of smoe_ssim.cuh and reads dL/dq
+// back for the reverse sweep.
+template <int D, int C, int PXL, bool TRAIN, bool SSIM = false>
 __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     using L = SL<D, C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -312,6 +316,46 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     // ---- 4. clip + fake quant, loss, dL/dy (smoe.py:857,899,905-937) ----------------------------------
     float Gc[PXL][C], dot[PXL];
     float loss_part = 0.0f, sse_part = 0.0f;
+    if constexpr (SSIM) {
+        float* s_ss = lds + a.ssim_off;
+        const int bh = a.batch_shape[0], bw = a.batch_shape[1];
+        const float* s_Tr = s_ss;
+        const float* s_Tc = s_ss + 11 * bh;
+        float* s_X = s_ss + ((11 * (bh + bw) + 3) & ~3);
+        float* s_Y = s_X + C * Nb;
+        float* s_Wa = s_Y + C * Nb;
+        float* s_Wb = s_Wa + 5 * Nb;
+        for (int i = tid; i < 11 * (bh + bw); i += SH_THREADS) s_ss[i] = a.ssim_T[i];
+        bool ste[PXL][C];
+#pragma unroll
+        for (int p = 0; p < PXL; ++p) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float yc = __builtin_amdgcn_fmed3f(y[p][c], 0.0f, a.kc.nudged_max);
+                const float q = floorf(fmaf(yc, a.kc.inv_scale, 0.5f)) * a.kc.scale;
+                const float diff = q - t[p][c];
+                ste[p][c] = pv[p] && (yc == y[p][c]);
+                if (pv[p]) {
+                    sse_part = fmaf(diff, diff, sse_part);
+                    if (a.recon != nullptr) a.recon[((size_t)b * C + c) * Nb + p * SH_THREADS + tid] = q;
+                    s_X[c * Nb + p * SH_THREADS + tid] = q;
+                    s_Y[c * Nb + p * SH_THREADS + tid] = t[p][c];
+                }
+            }
+        }
+        __syncthreads();
+        loss_part = ssim_block<C, TRAIN, SH_THREADS>(s_X, s_Y, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, Nb, tid);
+#pragma unroll
+        for (int p = 0; p < PXL; ++p) {
+            dot[p] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                Gc[p][c] = (TRAIN && ste[p][c]) ? s_X[c * Nb + p * SH_THREADS + tid] : 0.0f;
+                dot[p] = fmaf(Gc[p][c], y[p][c], dot[p]);
+            }
+            dot[p] = (S[p] > 10e-12f) ? dot[p] : 0.0f;
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < PXL; ++p) {
         dot[p] = 0.0f;
@@ -332,6 +376,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             dot[p] = fmaf(Gc[p][c], y[p][c], dot[p]);
         }
         dot[p] = (S[p] > 10e-12f) ? dot[p] : 0.0f;
+    }
     }
 
     // ---- 5. sweep C: reverse pass, raw sums per kernel (smoe.py:1148-1150) ---------
@@ -401,6 +446,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     __syncthreads();
     if (tid == 0) {
         float lossv = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (SSIM) lossv += 1.0f;                                      // smoe.py:1010: 1 - ssim
         if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {                    // smoe.py:1027,1044 over the batch's active kernels
             for (int i = 0; i < Kact; ++i) {
                 const int k = s_list[i];
@@ -567,13 +613,26 @@ size_t shared_lds_bytes(int D, int C, int K, int KW) {
     const int TRI = D * (D + 1) / 2;
     const int SP = TRI + D + 1 + C + D * C;
     const int PK = 1 + D + TRI + C + D * C;
-    return sizeof(float) * ((size_t)K + SH_KC * SP + 4 * SH_KC * PK + K + 8 + 8 + KW);
+    return sizeof(float) * (((size_t)K + SH_KC * SP + 4 * SH_KC * PK + K + 8 + 8 + KW + 3) & ~(size_t)3);
+}
+
+// ssim_opt: tap tables + X, Y [C][Nb] + Wa [5][Nb] + Wb [3][Nb] behind the regular carve-up
+size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw) {
+    return sizeof(float) * ((size_t)((11 * (bh + bw) + 3) & ~3) + (size_t)(2 * C + 8) * Nb);
 }
 
 template <int D, int C, int PXL>
 static hipError_t launch_pass_t(const SharedArgs& a, bool train, hipStream_t st) {
-    const size_t shm = shared_lds_bytes(D, C, a.K, a.KW);
+    size_t shm = shared_lds_bytes(D, C, a.K, a.KW);
     auto kern = train ? shared_pass_kernel<D, C, PXL, true> : shared_pass_kernel<D, C, PXL, false>;
+    if constexpr (D == 2) {
+        if (a.ssim) {
+            kern = train ? shared_pass_kernel<D, C, PXL, true, true> : shared_pass_kernel<D, C, PXL, false, true>;
+            shm += shared_ssim_lds_bytes(C, a.Nb, a.batch_shape[0], a.batch_shape[1]);
+        }
+    } else {
+        if (a.ssim) return hipErrorNotSupported;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.NB), dim3(SH_THREADS), shm, st, a);

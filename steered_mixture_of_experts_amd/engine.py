@@ -277,6 +277,7 @@ class SharedConfig:
     start_pis: int = 0
     only_y_gamma: bool = False
     overlap: int = 0
+    ssim_opt: bool = False
     quantization_mode: int = 0
     quantize_pis: bool = False
     bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
@@ -312,6 +313,7 @@ class SharedEngine:
         c.start_pis = cfg.start_pis or cfg.kernels
         c.only_y_gamma = int(cfg.only_y_gamma)
         c.overlap = int(cfg.overlap)
+        c.ssim_opt = int(cfg.ssim_opt)
         c.quantization_mode, c.quantize_pis = int(cfg.quantization_mode), int(cfg.quantize_pis)
         for i in range(5):
             c.bit_depths[i] = int(cfg.bit_depths[i])

@@ -610,7 +610,7 @@ class SharedSmoe:
                  batch_size=None, train_gammas=True, train_musx=True, use_determinant=False, normalize_pis=True,
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
                  engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
-                 upper_bounds=None, only_y_gamma=False, use_diff_center=False, **unsupported):
+                 upper_bounds=None, only_y_gamma=False, use_diff_center=False, ssim_opt=False, **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
@@ -632,7 +632,10 @@ class SharedSmoe:
         self.bit_depths = [20, 18, 6, 10, 10] if bit_depths is None else list(bit_depths)
         self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
         self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
-        self.ssim_opt = self.radial_as = False
+        self.radial_as = False
+        self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
+        if self.ssim_opt and (image.ndim - 1 != 2 or quantization_mode >= 2):
+            raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images, without quantization_mode 2")
         self.only_y_gamma = bool(only_y_gamma) and self.use_yuv          # smoe_test.py:43-44, smoe.py:725-729
         self.use_diff_center = bool(use_diff_center)
         if quantization_mode >= 2 and use_diff_center:
@@ -701,7 +704,7 @@ class SharedSmoe:
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
             start_pis=self.kernels, overlap=self.overlap, quantization_mode=self.quantization_mode,
             quantize_pis=self.quantize_pis, bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
-            upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma)
+            upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma, ssim_opt=self.ssim_opt)
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:

@@ -293,9 +293,9 @@ def test_training_cli_mirrors_the_reference_flags(tmp_path):
         q = cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "2", "-bz", "16", "16",
                                         "-n", "2", "-v", "2", "-ssim", "true"]))
         assert q.ssim_opt and 0.0 < q.get_losses()[-1][1] < 1.0            # 1 - SSIM
-        with pytest.raises(NotImplementedError):
-            cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "3", "-bz", "16", "16",
-                                        "-ssim", "true", "--mode", "shared"]))
+        gs = cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "3", "-bz", "16", "16",
+                                         "-n", "2", "-v", "2", "-ssim", "true", "--mode", "shared"]))
+        assert gs.ssim_opt and 0.0 < gs.get_losses()[-1][1] < 1.0
         with pytest.raises(NotImplementedError):
             cli.main(parser.parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-is", "100"]))
     finally:
@@ -467,3 +467,22 @@ def test_radial_steering_through_the_facade(ic):
     r = Smoe(img, init_params=got, batch_size=[16, 16], use_determinant=True, radial_as=True, train_inverse_cov=ic,
              engine_factory=OracleEngine)                    # the (K,) layout round-trips through init_params
     assert np.array_equal(r.get_reconstruction(), s.get_reconstruction())
+
+
+def test_shared_facade_with_the_ssim_loss():
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(32, 48, seed=11)
+    s = SharedSmoe(img, kernels_per_dim=[4, 5], batch_size=[16, 16], use_determinant=True, ssim_opt=True,
+                   engine_factory=OracleSharedEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(4, val_iter=2)
+    p0 = o.shared_init_params(img, [4, 5])
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=20, lr_steer=0.01, ssim_opt=True)
+    pn, _, info = o.shared_fit(p0, tb.reshape(6, -1, 1), o.global_batch_coords((32, 48), (16, 16)), cfg, 4, val_iter=2)
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
+    assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
+    assert 0 < s.get_losses()[-1][1] < s.get_losses()[0][1] < 1

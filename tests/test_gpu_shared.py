@@ -329,3 +329,36 @@ def test_shared_fake_quantised_variables(shape, bshape, C, kpd, yuv, mode):
     with pytest.raises(_lib.SmoeError) as e:
         _engine(shape, bshape, C, K, yuv, quantization_mode=3)
     assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("shape,bshape,C,kpd,yuv,ov", [((64, 64), (16, 16), 1, [4, 4], False, 0),
+                                                       ((64, 96), (32, 32), 3, [3, 5], True, 0),
+                                                       ((96, 64), (32, 64), 1, [6, 4], False, 0),
+                                                       ((48, 40), (16, 8), 1, [12, 12], False, 3)])
+def test_shared_ssim_loss(shape, bshape, C, kpd, yuv, ov):
+    """ssim_opt in the shared-kernel mode: loss_pixel = 1 - SSIM of every batch (smoe.py:980-1011; with a halo the
+    interior is cropped first, smoe.py:984-991), gradients accumulated over the batches."""
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, pis_l1=0.05, u_l1=0.001, ssim_opt=True)
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, yuv, pis_l1=0.05, u_l1=0.001, ssim_opt=True, overlap=ov)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True, update_lists=False)
+    torch.cuda.synchronize()
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    f64 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float64, want_grads=True, q_override=recon)
+    assert np.abs(fw["loss"].cpu().numpy() - f64["loss"]).max() < 2e-5
+    g64 = {k: v.sum(axis=0) for k, v in f64["grads"].items()}
+    st = eng.new_adam_state(dp)
+    loss = torch.zeros(NB, device="cuda")
+    eng.accumulate(T, dp, dl, loss_out=loss)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    assert np.abs(loss.cpu().numpy() - f64["loss"]).max() < 2e-5
+    bad = (np.abs(f64["w"] - 0.5 / 256) < 1e-6).any() or ((np.abs(f64["y"]) < 1e-6) | (np.abs(f64["y"] - 1) < 1e-6)).any()
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g64[name]).max() + 1e-30
+        err = np.abs(st.m[name].cpu().numpy() / 0.1 - g64[name]).max() / scale
+        assert err < (2e-3 if bad else 1e-4), (name, err)
+    eng.close()
