@@ -636,7 +636,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         const double w = cfg->use_yuv ? ((ch == 0) ? 6.0 / 8.0 : 1.0 / 8.0) : 1.0 / (double)C;
         kc.sw[ch] = (float)(w / (double)Nb);
     }
-    kc.inverse_cov = 0;                       // train_inverse_cov / radial_as are not built for the shared-kernel mode
+    kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;   // radial_as is not built for the shared-kernel mode
     kc.radial = 0;
     kc.kcount_norm = 0;
     kc.pis_l1_raw = cfg->pis_l1;

@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
 
     // stage chunk [c0, c0+n) of the active list into LDS (derived quantities, smoe.py:732-733,809-819);
     // a list that fits one chunk (the common case after pruning) is staged once for all three sweeps
+    const bool ic = a.kc.inverse_cov != 0;
     int staged_c0 = -1;
     auto stage = [&](int c0, int n) {
         if (c0 == staged_c0) return;
@@ -158,13 +159,18 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                 for (int m = 0; m <= l; ++m) {
                     A[l][m] = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
                     if (l == m) det *= A[l][m];
-                    r[L::O_AS + tri(l, m)] = SQ * A[l][m];
+                    // train_inverse_cov: the coefficients c_lm of r^T A' r over l >= m, A' = SQ^2 A (smoe.py:734-735,791-793)
+                    r[L::O_AS + tri(l, m)] = ic ? ((l == m) ? SQ * SQ : 2.0f * SQ * SQ) * A[l][m] : SQ * A[l][m];
                 }
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 float cz = 0.0f;
+                if (ic) {
+                    cz = fqv(a.p.musX[(size_t)k * D + m], a.kc, 1);        // the centre itself: r = x - mu per pixel
+                } else {
 #pragma unroll
-                for (int l = m; l < D; ++l) cz = fmaf(fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * A[l][m], cz);
+                    for (int l = m; l < D; ++l) cz = fmaf(fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * A[l][m], cz);
+                }
                 r[L::O_CZ + m] = cz;
             }
             const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
@@ -181,6 +187,17 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     // g_k(x) * 1 and z' for one pixel
     auto gate = [&](const float* r, const float (&xx)[D], float (&z)[D]) -> float {
         float maha = 0.0f;
+        if (ic) {                                  // z := r = x - mu ; maha' = sum_{l>=m} c_lm r_l r_m
+#pragma unroll
+            for (int l = 0; l < D; ++l) {
+                z[l] = xx[l] - r[L::O_CZ + l];
+                float tq = 0.0f;
+#pragma unroll
+                for (int m = 0; m <= l; ++m) tq = fmaf(r[L::O_AS + tri(l, m)], z[m], tq);
+                maha = fmaf(tq, z[l], maha);
+            }
+            return r[L::O_COEF] * fexp2(-maha);
+        }
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             float zz = -r[L::O_CZ + m];
@@ -251,6 +268,32 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     // ---- 3b. halo (overlap_of_batches > 0): the window's extra pixels take part in the influence test
     // only (smoe.py:829 runs on the whole window, the loss is cropped, smoe.py:909-923); a window pixel
     // outside the image has all-zero coordinates (np.pad of the joint domain, smoe.py:21,28)
+    // maha' (in exp2 units) and prod(diag A) of kernel k at a halo pixel, straight from global memory
+    auto halo_maha = [&](int k, const float (&xh)[D], float& maha, float& det) {
+        float Aq[D][D], rr[D];
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            rr[l] = xh[l] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1);
+#pragma unroll
+            for (int m = 0; m <= l; ++m) {
+                Aq[l][m] = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
+                if (l == m) det *= Aq[l][m];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            float zz = 0.0f;
+            if (ic) {
+#pragma unroll
+                for (int l = 0; l < D; ++l) zz = fmaf(rr[l], (SQ * SQ) * ((l >= m) ? Aq[l][m] : Aq[m][l]), zz);
+                maha = fmaf(zz, rr[m], maha);
+            } else {
+#pragma unroll
+                for (int l = m; l < D; ++l) zz = fmaf(rr[l], SQ * Aq[l][m], zz);
+                maha = fmaf(zz, zz, maha);
+            }
+        }
+    };
     if (a.overlap > 0) {
         int ext[D], next = 1;
 #pragma unroll
@@ -277,17 +320,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int i = 0; i < Kact; ++i) {
                 const int k = s_list[i];
                 float maha = 0.0f, det = 1.0f;
-#pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    float zz = 0.0f;
-#pragma unroll
-                    for (int l = m; l < D; ++l) {
-                        const float Alm = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
-                        if (l == m) det *= Alm;
-                        zz = fmaf(xh[l] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * Alm, zz);
-                    }
-                    maha = fmaf(zz, zz, maha);
-                }
+                halo_maha(k, xh, maha, det);
                 const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
                 Sh += nq * fqv(a.p.pis[k], a.kc, 3) * fexp2(-maha);
             }
@@ -295,17 +328,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int i = 0; i < Kact; ++i) {
                 const int k = s_list[i];
                 float maha = 0.0f, det = 1.0f;
-#pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    float zz = 0.0f;
-#pragma unroll
-                    for (int l = m; l < D; ++l) {
-                        const float Alm = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
-                        if (l == m) det *= Alm;
-                        zz = fmaf(xh[l] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * Alm, zz);
-                    }
-                    maha = fmaf(zz, zz, maha);
-                }
+                halo_maha(k, xh, maha, det);
                 const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
                 if (nq * fqv(a.p.pis[k], a.kc, 3) * fexp2(-maha) * invh > a.kc.tau) s_flag[i] = 1;
             }
@@ -408,12 +431,22 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                     }
                     const float u = pv[p] ? fmaf(wt, eg, -(w * dot[p])) : 0.0f;
                     acc[L::R_SU] += u;
+                    if (ic) {                              // raw sums of u r_l and u r_l r_m
+#pragma unroll
+                        for (int l = 0; l < D; ++l) {
+                            const float ur = u * z[l];
+                            acc[L::R_SUZ + l] += ur;
+#pragma unroll
+                            for (int m = 0; m <= l; ++m) acc[L::R_SXZ + tri(l, m)] = fmaf(ur, z[m], acc[L::R_SXZ + tri(l, m)]);
+                        }
+                    } else {
 #pragma unroll
                     for (int m = 0; m < D; ++m) {
                         const float uz = u * z[m];
                         acc[L::R_SUZ + m] += uz;
 #pragma unroll
                         for (int l = m; l < D; ++l) acc[L::R_SXZ + tri(l, m)] = fmaf(x[p][l], uz, acc[L::R_SXZ + tri(l, m)]);
+                    }
                     }
                 }
 #pragma unroll
@@ -510,9 +543,10 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
         }
     }
     const float su = r[L::R_SU];
+    const bool ic = a.kc.inverse_cov != 0;        // train_inverse_cov: suz holds sum u r_l, sxz holds sum u r_l r_m
     float suz[D];
 #pragma unroll
-    for (int m = 0; m < D; ++m) suz[m] = r[L::R_SUZ + m] * INV_SQ;
+    for (int m = 0; m < D; ++m) suz[m] = ic ? r[L::R_SUZ + m] : r[L::R_SUZ + m] * INV_SQ;
     // pis (optimizer2)
     if (a.train_pis) {
         float g = (pi > 0.0f ? su / pi : 0.0f) + nact * a.reg_pi;
@@ -524,8 +558,13 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
 #pragma unroll
         for (int l = 0; l < D; ++l) {
             float g = 0.0f;
+            if (ic) {                             // d/dmu_l = sum_m A_lm sur_m with the symmetric A
 #pragma unroll
-            for (int m = 0; m <= l; ++m) g = fmaf(A[l][m], suz[m], g);
+                for (int m = 0; m < D; ++m) g = fmaf((l >= m) ? A[l][m] : A[m][l], suz[m], g);
+            } else {
+#pragma unroll
+                for (int m = 0; m <= l; ++m) g = fmaf(A[l][m], suz[m], g);
+            }
             g = fq_pass(mu_raw[l], a.kc, 1) ? g : 0.0f;
             const size_t o = (size_t)k * D + l;
             adam_apply(&a.p.musX[o], &a.m.musX[o], &a.v.musX[o], g, a.lr_expert, a);
@@ -536,7 +575,8 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
     for (int l = 0; l < D; ++l)
 #pragma unroll
         for (int m = 0; m <= l; ++m) {
-            float g = fmaf(mu[l], suz[m], -(r[L::R_SXZ + tri(l, m)] * INV_SQ));
+            float g = ic ? ((l == m) ? -0.5f * r[L::R_SXZ + tri(l, m)] : -r[L::R_SXZ + tri(l, m)])
+                         : fmaf(mu[l], suz[m], -(r[L::R_SXZ + tri(l, m)] * INV_SQ));
             const size_t o = ((size_t)k * D + l) * D + m;
             if (l == m) {
                 if (a.use_det) g += su / A[l][l];
@@ -597,9 +637,15 @@ __global__ void shared_readmit_kernel(SharedReadmitArgs a) {
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             float zz = 0.0f;
+            if (a.kc.inverse_cov) {
 #pragma unroll
-            for (int l = m; l < D; ++l) zz = fmaf(r[l], A[l][m], zz);
-            maha = fmaf(zz, zz, maha);
+                for (int l = 0; l < D; ++l) zz = fmaf(r[l], (l >= m) ? A[l][m] : A[m][l], zz);
+                maha = fmaf(zz, r[m], maha);
+            } else {
+#pragma unroll
+                for (int l = m; l < D; ++l) zz = fmaf(r[l], A[l][m], zz);
+                maha = fmaf(zz, zz, maha);
+            }
         }
         near = near || (maha < 800.0f);
     }

@@ -278,6 +278,7 @@ class SharedConfig:
     only_y_gamma: bool = False
     overlap: int = 0
     ssim_opt: bool = False
+    train_inverse_cov: bool = False
     quantization_mode: int = 0
     quantize_pis: bool = False
     bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
@@ -314,6 +315,7 @@ class SharedEngine:
         c.only_y_gamma = int(cfg.only_y_gamma)
         c.overlap = int(cfg.overlap)
         c.ssim_opt = int(cfg.ssim_opt)
+        c.train_inverse_cov = int(cfg.train_inverse_cov)
         c.quantization_mode, c.quantize_pis = int(cfg.quantization_mode), int(cfg.quantize_pis)
         for i in range(5):
             c.bit_depths[i] = int(cfg.bit_depths[i])

@@ -610,7 +610,8 @@ class SharedSmoe:
                  batch_size=None, train_gammas=True, train_musx=True, use_determinant=False, normalize_pis=True,
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
                  engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
-                 upper_bounds=None, only_y_gamma=False, use_diff_center=False, ssim_opt=False, **unsupported):
+                 upper_bounds=None, only_y_gamma=False, use_diff_center=False, ssim_opt=False, train_inverse_cov=True,
+                 **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
@@ -633,6 +634,7 @@ class SharedSmoe:
         self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
         self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
         self.radial_as = False
+        self.train_inverse_cov = bool(train_inverse_cov)                  # smoe.py:41: the constructor default is True
         self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
         if self.ssim_opt and (image.ndim - 1 != 2 or quantization_mode >= 2):
             raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images, without quantization_mode 2")
@@ -666,7 +668,7 @@ class SharedSmoe:
             kpd = list(kernels_per_dim)
             if len(kpd) == 1:
                 kpd = kpd * d
-            p0 = {k: v[0] for k, v in blk.init_block_params(image[None], kpd, normalize_pis).items()}
+            p0 = {k: v[0] for k, v in blk.init_block_params(image[None], kpd, normalize_pis, self.train_inverse_cov).items()}
             self.musX_init = blk.gen_domain_grid(kpd, d)
         self.kernels = self.start_pis = self.kernel_count = p0["pis"].shape[0]
         # use_diff_center (smoe.py:390-394,746-747): the trained variable is the offset from the kernel grid; the
@@ -704,7 +706,8 @@ class SharedSmoe:
             grad_clip=float(self.grad_clip_value_abs or 0.0), pis_l1=float(pis_l1), u_l1=float(u_l1),
             start_pis=self.kernels, overlap=self.overlap, quantization_mode=self.quantization_mode,
             quantize_pis=self.quantize_pis, bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
-            upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma, ssim_opt=self.ssim_opt)
+            upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma, ssim_opt=self.ssim_opt,
+            train_inverse_cov=self.train_inverse_cov)
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:

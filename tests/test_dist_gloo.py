@@ -32,7 +32,7 @@ out = {"params": s.get_params(), "losses": s.get_losses(), "mses": s.get_mses(),
 # shared-kernel mode: batches sharded, accumulated gradient buffer all-reduced before the Adam step
 from fake_engine import OracleSharedEngine
 from steered_mixture_of_experts_amd.smoe import SharedSmoe
-g = SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True, engine_factory=OracleSharedEngine)
+g = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True, engine_factory=OracleSharedEngine)
 g.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
 g.train(4, val_iter=2)
 out["shared"] = {"params": g.get_params(), "losses": g.get_losses(), "recon": g.get_reconstruction(),

@@ -183,7 +183,7 @@ def test_shared_kernel_facade_matches_the_numpy_restatement():
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import SharedSmoe
     img = _image(64, 48)
-    s = SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[16, 16], use_determinant=True,
+    s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[4, 3], batch_size=[16, 16], use_determinant=True,
                    engine_factory=OracleSharedEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
     assert s.num_batches == 12 and s.kernels == 12
@@ -203,7 +203,7 @@ def test_shared_kernel_facade_matches_the_numpy_restatement():
     assert s.get_reconstruction().shape == img.shape and s.get_weight_matrix_argmax().max() < 12
     assert np.array_equal(np.array(s.kernel_list_per_batch), info["lists"])
     with pytest.raises(ValueError):
-        SharedSmoe(img, kernels_per_dim=[4, 3], batch_size=[10, 16], engine_factory=OracleSharedEngine)
+        SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[4, 3], batch_size=[10, 16], engine_factory=OracleSharedEngine)
 
 
 def test_shared_facade_with_overlapping_batches():
@@ -212,7 +212,7 @@ def test_shared_facade_with_overlapping_batches():
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import SharedSmoe
     img = _image(64, 48, seed=4)
-    s = SharedSmoe(img, kernels_per_dim=[8, 6], batch_size=[16, 16], use_determinant=True, overlap_of_batches=3,
+    s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[8, 6], batch_size=[16, 16], use_determinant=True, overlap_of_batches=3,
                    engine_factory=OracleSharedEngine)
     assert s.batch_size == (22, 22) and s.batch_size_valued == (16, 16) and s.overlap == 3        # smoe.py:244-245
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
@@ -367,7 +367,7 @@ def test_shared_facade_with_fake_quantised_variables(mode):
     img = _image(32, 48, seed=6)
     kw = dict(quantization_mode=mode, quantize_pis=True, bit_depths=[14, 12, 8, 10, 10],
               lower_bounds=[-60, -.3, -1, 0, -4], upper_bounds=[60, 1.3, 2, 2, 4])
-    s = SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True,
+    s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True,
                    engine_factory=OracleSharedEngine, **kw)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
     s.train(6, val_iter=3)
@@ -384,7 +384,7 @@ def test_shared_facade_with_fake_quantised_variables(mode):
     assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
     for bad in (1, 3):
         with pytest.raises(NotImplementedError):
-            SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], engine_factory=OracleSharedEngine,
+            SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[3, 4], batch_size=[16, 16], engine_factory=OracleSharedEngine,
                        quantization_mode=bad)
 
 
@@ -393,7 +393,7 @@ def test_shared_facade_only_y_gamma_and_diff_center():
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import SharedSmoe
     img = _image(32, 32, C=3, seed=2)
-    s = SharedSmoe(img, kernels_per_dim=[3, 3], batch_size=[16, 16], use_determinant=True, use_yuv=True,
+    s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[3, 3], batch_size=[16, 16], use_determinant=True, use_yuv=True,
                    only_y_gamma=True, use_diff_center=True, engine_factory=OracleSharedEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
     assert np.array_equal(s.get_params()["musX"], np.zeros((9, 2), np.float32))      # offsets start at zero
@@ -473,7 +473,7 @@ def test_shared_facade_with_the_ssim_loss():
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import SharedSmoe
     img = _image(32, 48, seed=11)
-    s = SharedSmoe(img, kernels_per_dim=[4, 5], batch_size=[16, 16], use_determinant=True, ssim_opt=True,
+    s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[4, 5], batch_size=[16, 16], use_determinant=True, ssim_opt=True,
                    engine_factory=OracleSharedEngine)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
     s.train(4, val_iter=2)
@@ -486,3 +486,23 @@ def test_shared_facade_with_the_ssim_loss():
         assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
     assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
     assert 0 < s.get_losses()[-1][1] < s.get_losses()[0][1] < 1
+
+
+def test_shared_facade_inverse_covariance_default():
+    """SharedSmoe mirrors the reference constructor default train_inverse_cov=True (A_init squared, maha = r^T A r)."""
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(32, 48, seed=14)
+    s = SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True, engine_factory=OracleSharedEngine)
+    assert s.train_inverse_cov and np.allclose(s.get_params()["A_diagonal"][:, 0, 0], 64.0)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    s.train(4, val_iter=2)
+    p0 = o.shared_init_params(img, [3, 4])
+    p0["A_diagonal"] = p0["A_diagonal"] ** 2
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=12, lr_steer=0.05, train_inverse_cov=True)
+    pn, _, info = o.shared_fit(p0, tb.reshape(6, -1, 1), o.global_batch_coords((32, 48), (16, 16)), cfg, 4, val_iter=2)
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
+    assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)

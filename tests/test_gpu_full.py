@@ -250,7 +250,7 @@ def test_end_to_end_fit_quality_on_a_smooth_image():
     assert b.get_psnr() > p0 + 4.0, (p0, b.get_psnr())
     assert [i for i, _ in b.get_losses()] == [0, 100, 200, 300]
     assert b.get_losses()[-1][1] < b.get_losses()[0][1]
-    s = SharedSmoe(img, kernels_per_dim=[8, 8], batch_size=[32, 32], use_determinant=True)
+    s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[8, 8], batch_size=[32, 32], use_determinant=True)
     s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
     q0 = s.get_psnr()
     s.train(300, val_iter=100)

@@ -200,7 +200,7 @@ def test_shared_facade_on_gpu_matches_the_oracle_backed_facade():
     img = _image((64, 96), 1, 77)
 
     def run(factory):
-        s = SharedSmoe(img, kernels_per_dim=[4, 6], batch_size=[16, 32], use_determinant=True, engine_factory=factory)
+        s = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[4, 6], batch_size=[16, 32], use_determinant=True, engine_factory=factory)
         s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
         s.train(10, val_iter=5)
         return s
@@ -361,4 +361,49 @@ def test_shared_ssim_loss(shape, bshape, C, kpd, yuv, ov):
         scale = np.abs(g64[name]).max() + 1e-30
         err = np.abs(st.m[name].cpu().numpy() / 0.1 - g64[name]).max() / scale
         assert err < (2e-3 if bad else 1e-4), (name, err)
+    eng.close()
+
+
+@pytest.mark.parametrize("shape,bshape,C,kpd,yuv,ov", [((64, 64), (16, 16), 1, [4, 4], False, 2),
+                                                       ((64, 96), (32, 32), 3, [3, 5], True, 0),
+                                                       ((32, 32, 8), (16, 16, 4), 3, [2, 2, 2], True, 0)])
+def test_shared_inverse_covariance_form(shape, bshape, C, kpd, yuv, ov):
+    """train_inverse_cov in the shared-kernel mode (smoe.py:734-735,791-793): forward, kernel lists (with a halo),
+    accumulated gradients, readmission."""
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, pis_l1=0.05, u_l1=0.001, train_inverse_cov=True)
+    p["A_diagonal"] = (p["A_diagonal"] ** 2).astype(np.float32)
+    p["A_corr"] = (p["A_corr"] * 3.0).astype(np.float32)
+    lists = np.ones((NB, K), bool)
+    halo = o.global_halo_coords(shape, bshape, ov) if ov else None
+    ref = o.shared_pass(p, tgt, coords, lists, cfg, np.float32, halo_coords=halo)
+    eng = _engine(shape, bshape, C, K, yuv, pis_l1=0.05, u_l1=0.001, train_inverse_cov=True, overlap=ov)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True)
+    torch.cuda.synchronize()
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    f64 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float64, want_grads=True, q_override=recon)
+    assert np.allclose(fw["loss"].cpu().numpy(), f64["loss"], rtol=3e-5)
+    near_tau = (np.abs(f64["w"] - 0.5 / 256) < 1e-6).any(axis=2)
+    if not ov:
+        assert (_mask(dl.cpu().numpy().view(np.uint32), K) == ref["lists_new"])[~near_tau].all()
+    else:
+        assert (_mask(dl.cpu().numpy().view(np.uint32), K) == ref["lists_new"]).mean() > 0.995
+    g64 = {k: v.sum(axis=0) for k, v in f64["grads"].items()}
+    st = eng.new_adam_state(dp)
+    full = eng.new_lists()
+    eng.accumulate(T, dp, full)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    bad = near_tau.any() or ((np.abs(f64["y"]) < 1e-6) | (np.abs(f64["y"] - 1) < 1e-6)).any()
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g64[name]).max() + 1e-30
+        err = np.abs(st.m[name].cpu().numpy() / 0.1 - g64[name]).max() / scale
+        assert err < (2e-3 if bad else 5e-5), (name, err)
+    got = {k: v.cpu().numpy()[None] for k, v in dp.items()}
+    empty = torch.zeros_like(dl)
+    eng.update_kernel_list(dp, empty)
+    want = o.shared_readmit(got, np.zeros((NB, K), bool), coords if halo is None else halo, cfg, np.float32)
+    assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want)
     eng.close()
