@@ -214,6 +214,7 @@ typedef struct smoe_shared_config {
     float   upper_bounds[5];
     int32_t ssim_opt;                   /* loss_pixel = 1 - SSIM of every batch (2-d, >= 5 pixels per axis)  smoe.py:980-1011 */
     int32_t train_inverse_cov;          /* as smoe_config                                       smoe.py:734-735,791-793 */
+    int32_t radial_as;                  /* as smoe_config: A_diagonal [K,d,d] with equal diagonals        smoe.py:714-719 */
 } smoe_shared_config;
 
 typedef struct smoe_shared_context* smoe_shared_handle;

@@ -522,6 +522,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         if (cfg->quantization_mode == 3)
             return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: quantization_mode 3 (image-wide min/max ranges) is not built for the shared-kernel mode");
     }
+    if (cfg->radial_as && cfg->quantization_mode >= 2)
+        return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: radial_as with quantization_mode 2/3 is not built");
     if (cfg->ssim_opt) {
         if (cfg->dim != 2) return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt is built for 2-d batches only");
         if (cfg->batch_shape[0] < 5 || cfg->batch_shape[1] < 5)
@@ -636,8 +638,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         const double w = cfg->use_yuv ? ((ch == 0) ? 6.0 / 8.0 : 1.0 / 8.0) : 1.0 / (double)C;
         kc.sw[ch] = (float)(w / (double)Nb);
     }
-    kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;   // radial_as is not built for the shared-kernel mode
-    kc.radial = 0;
+    kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;
+    kc.radial = cfg->radial_as ? 1 : 0;
     kc.kcount_norm = 0;
     kc.pis_l1_raw = cfg->pis_l1;
     *out = h;

@@ -571,22 +571,35 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
         }
     }
     // steering (optimizer3)
+    float gA[D][D];
 #pragma unroll
     for (int l = 0; l < D; ++l)
 #pragma unroll
         for (int m = 0; m <= l; ++m) {
             float g = ic ? ((l == m) ? -0.5f * r[L::R_SXZ + tri(l, m)] : -r[L::R_SXZ + tri(l, m)])
                          : fmaf(mu[l], suz[m], -(r[L::R_SXZ + tri(l, m)] * INV_SQ));
-            const size_t o = ((size_t)k * D + l) * D + m;
             if (l == m) {
                 if (a.use_det) g += su / A[l][l];
                 g += nact * a.reg_u;
             }
-            g = fq_pass(Araw[l][m], a.kc, 0) ? g : 0.0f;
+            gA[l][m] = fq_pass(Araw[l][m], a.kc, 0) ? g : 0.0f;
+        }
+    if (a.kc.radial) {        // radial_as (smoe.py:714-719): one value per kernel -> its gradient is the trace; A_corr untrained
+        float tr = 0.0f;
+#pragma unroll
+        for (int l = 0; l < D; ++l) tr += gA[l][l];
+#pragma unroll
+        for (int l = 0; l < D; ++l) gA[l][l] = tr;
+    }
+#pragma unroll
+    for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int m = 0; m <= l; ++m) {
+            const size_t o = ((size_t)k * D + l) * D + m;
             if (l == m) {
-                adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], g, a.lr_steer, a);
-            } else {
-                adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], g, a.lr_steer, a);
+                adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], gA[l][m], a.lr_steer, a);
+            } else if (!a.kc.radial) {
+                adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], gA[l][m], a.lr_steer, a);
             }
         }
     // experts (optimizer1)

@@ -279,6 +279,7 @@ class SharedConfig:
     overlap: int = 0
     ssim_opt: bool = False
     train_inverse_cov: bool = False
+    radial_as: bool = False
     quantization_mode: int = 0
     quantize_pis: bool = False
     bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
@@ -316,6 +317,7 @@ class SharedEngine:
         c.overlap = int(cfg.overlap)
         c.ssim_opt = int(cfg.ssim_opt)
         c.train_inverse_cov = int(cfg.train_inverse_cov)
+        c.radial_as = int(cfg.radial_as)
         c.quantization_mode, c.quantize_pis = int(cfg.quantization_mode), int(cfg.quantize_pis)
         for i in range(5):
             c.bit_depths[i] = int(cfg.bit_depths[i])

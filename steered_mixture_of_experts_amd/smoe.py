@@ -611,7 +611,7 @@ class SharedSmoe:
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
                  engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
                  upper_bounds=None, only_y_gamma=False, use_diff_center=False, ssim_opt=False, train_inverse_cov=True,
-                 **unsupported):
+                 radial_as=False, **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
@@ -633,7 +633,9 @@ class SharedSmoe:
         self.bit_depths = [20, 18, 6, 10, 10] if bit_depths is None else list(bit_depths)
         self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
         self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
-        self.radial_as = False
+        self.radial_as = bool(radial_as)                                   # smoe.py:429-434,714-719
+        if self.radial_as and quantization_mode >= 1:
+            raise NotImplementedError("radial_as with a quantization mode is not built")
         self.train_inverse_cov = bool(train_inverse_cov)                  # smoe.py:41: the constructor default is True
         self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
         if self.ssim_opt and (image.ndim - 1 != 2 or quantization_mode >= 2):
@@ -670,6 +672,9 @@ class SharedSmoe:
                 kpd = kpd * d
             p0 = {k: v[0] for k, v in blk.init_block_params(image[None], kpd, normalize_pis, self.train_inverse_cov).items()}
             self.musX_init = blk.gen_domain_grid(kpd, d)
+        if self.radial_as:                    # one steering value per kernel: A_init[:, 0, 0] tiled over the diagonal
+            a0 = p0["A_diagonal"] if p0["A_diagonal"].ndim == 1 else p0["A_diagonal"][:, 0, 0]
+            p0["A_diagonal"] = np.ascontiguousarray(a0[:, None, None] * np.eye(d, dtype=np.float32))
         self.kernels = self.start_pis = self.kernel_count = p0["pis"].shape[0]
         # use_diff_center (smoe.py:390-394,746-747): the trained variable is the offset from the kernel grid; the
         # engine works on grid + offset, the getters subtract the grid
@@ -707,7 +712,7 @@ class SharedSmoe:
             start_pis=self.kernels, overlap=self.overlap, quantization_mode=self.quantization_mode,
             quantize_pis=self.quantize_pis, bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
             upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma, ssim_opt=self.ssim_opt,
-            train_inverse_cov=self.train_inverse_cov)
+            train_inverse_cov=self.train_inverse_cov, radial_as=self.radial_as)
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:
@@ -837,6 +842,8 @@ class SharedSmoe:
         out = {k: v.cpu().numpy().copy() for k, v in p.items()}
         if self._mus_grid is not None:                     # use_diff_center: report the trained offsets
             out["musX"] = out["musX"] - self._mus_grid
+        if self.radial_as:                                 # the reference's (K,) variable
+            out["A_diagonal"] = np.ascontiguousarray(out["A_diagonal"][:, 0, 0])
         return out
 
     def get_params(self):

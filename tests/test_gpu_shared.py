@@ -407,3 +407,33 @@ def test_shared_inverse_covariance_form(shape, bshape, C, kpd, yuv, ov):
     want = o.shared_readmit(got, np.zeros((NB, K), bool), coords if halo is None else halo, cfg, np.float32)
     assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want)
     eng.close()
+
+
+@pytest.mark.parametrize("ic", [False, True])
+def test_shared_radial_steering(ic):
+    """radial_as in the shared-kernel mode: tied diagonals (trace gradient, u_l1 counted d times), A_corr untouched."""
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False, perturb=True, pis_l1=0.05, u_l1=0.002,
+                                             radial_as=True, train_inverse_cov=ic)
+    a0 = np.abs(p["A_diagonal"][0, :, 0, 0]) ** (2 if ic else 1)
+    p["A_diagonal"] = (a0[None, :, None, None] * np.eye(2)).astype(np.float32)
+    p["A_corr"] = np.zeros_like(p["A_corr"])
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, False, pis_l1=0.05, u_l1=0.002, radial_as=True, train_inverse_cov=ic)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    recon = eng.forward(T, dp, dl, want_recon=True, update_lists=False)["recon"].cpu().numpy().transpose(0, 2, 1)
+    f64 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float64, want_grads=True, q_override=recon)
+    g64 = {k: v.sum(axis=0) for k, v in f64["grads"].items()}
+    st = eng.new_adam_state(dp)
+    eng.accumulate(T, dp, dl)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    m = {k: v.cpu().numpy() for k, v in st.m.items()}
+    scale = np.abs(g64["A_diagonal"]).max()
+    assert np.abs(m["A_diagonal"] / 0.1 - g64["A_diagonal"]).max() / scale < 1e-4
+    assert not m["A_corr"].any() and not dp["A_corr"].cpu().numpy().any()
+    dg = np.diagonal(dp["A_diagonal"].cpu().numpy(), axis1=-2, axis2=-1)
+    assert np.all(dg[:, 0] == dg[:, 1]) and np.abs(dg[:, 0] - a0).max() > 0.5
+    eng.close()
