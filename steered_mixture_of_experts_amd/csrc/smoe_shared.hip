@@ -72,7 +72,8 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // SSIM (ssim_opt, 2-d batches): loss_pixel = 1 - SSIM of the batch (smoe.py:980-1011); the quantised reconstruction and
 // the target of the batch go to LDS planes, the whole workgroup runs the SSIM stage of smoe_ssim.cuh and reads dL/dq
 // back for the reverse sweep.
-template <int D, int C, int PXL, bool TRAIN, bool SSIM = false>
+// IC: train_inverse_cov (compile-time, it sits in the per-pixel gate).
+template <int D, int C, int PXL, bool TRAIN, bool SSIM = false, bool IC = false>
 __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     using L = SL<D, C>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
 
     // stage chunk [c0, c0+n) of the active list into LDS (derived quantities, smoe.py:732-733,809-819);
     // a list that fits one chunk (the common case after pruning) is staged once for all three sweeps
-    const bool ic = a.kc.inverse_cov != 0;
+    constexpr bool ic = IC;
     int staged_c0 = -1;
     auto stage = [&](int c0, int n) {
         if (c0 == staged_c0) return;
@@ -683,10 +684,13 @@ size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw) {
 template <int D, int C, int PXL>
 static hipError_t launch_pass_t(const SharedArgs& a, bool train, hipStream_t st) {
     size_t shm = shared_lds_bytes(D, C, a.K, a.KW);
-    auto kern = train ? shared_pass_kernel<D, C, PXL, true> : shared_pass_kernel<D, C, PXL, false>;
+    const bool ic = a.kc.inverse_cov != 0;
+    auto kern = ic ? (train ? shared_pass_kernel<D, C, PXL, true, false, true> : shared_pass_kernel<D, C, PXL, false, false, true>)
+                   : (train ? shared_pass_kernel<D, C, PXL, true> : shared_pass_kernel<D, C, PXL, false>);
     if constexpr (D == 2) {
         if (a.ssim) {
-            kern = train ? shared_pass_kernel<D, C, PXL, true, true> : shared_pass_kernel<D, C, PXL, false, true>;
+            kern = ic ? (train ? shared_pass_kernel<D, C, PXL, true, true, true> : shared_pass_kernel<D, C, PXL, false, true, true>)
+                      : (train ? shared_pass_kernel<D, C, PXL, true, true> : shared_pass_kernel<D, C, PXL, false, true>);
             shm += shared_ssim_lds_bytes(C, a.Nb, a.batch_shape[0], a.batch_shape[1]);
         }
     } else {
