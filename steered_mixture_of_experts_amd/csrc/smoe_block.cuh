@@ -274,7 +274,8 @@ __device__ __forceinline__ float count_pis(const float* P) {
     return fmaxf(cnt, 1.0f);
 }
 
-// Replace the packed parameters P by the fake-quantised values the graph is built on.
+// Replace the packed parameters P by the fake-quantised values the graph is built on (forward and readmission
+// kernels: single pass; the fit kernel keeps a quantised LDS image instead, see refresh_quantised_image).
 // FULL = false: only the pis (quantize_pis, the reference CLI default) -- a few instructions, kept as a
 // run-time branch in the default kernels; modes 2 / 3 live in their own instantiations (QUANT) so that their
 // register footprint does not reach the hot kernels.
@@ -321,72 +322,6 @@ __device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc
             for (int c = 0; c < C; ++c) p[Lt::O_NU + c] = fq_val(p[Lt::O_NU + c], br.nu);
 #pragma unroll
             for (int i = 0; i < D * C; ++i) p[Lt::O_GA + i] = fq_val(p[Lt::O_GA + i], br.ga);
-        }
-    }
-}
-
-// Backward of the mode-3 fake-quant ops on this lane's partial gradients acc[] (linear, so it commutes with
-// the cross-lane sum): inside the nudged range the gradient passes; what falls below / above goes to the
-// min / max input and from there (reduce_min / reduce_max) to the extreme elements, split over ties.
-// (Fixed ranges -- pis, mode 2 -- are plain per-element masks and are applied by the slot owners on the
-// reduced totals.)  Praw: the block's RAW packed parameters.
-template <int D, int C, int K>
-__device__ __forceinline__ void route_quant_partials(const float* Praw, const KernelConsts& kc, float* __restrict__ acc) {
-    using Lt = Layout<D, C, K>;
-    if (kc.qmode == 3) {
-        bool keep[K];
-        const FqRange rp = fq_fixed(kc, 3);
-#pragma unroll
-        for (int k = 0; k < K; ++k) keep[k] = fq_val(Praw[k * Lt::PK + Lt::O_PI], rp) > 0.0f;
-        BlockRanges<D, C, K> br;
-        br.compute(Praw, keep, kc);
-        // per tensor t: sums of the gradients that fall below / above, tie counts at the raw extremes
-        float GL[5], GA[5], nlo[5], nhi[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) { GL[t] = GA[t] = 0.0f; nlo[t] = nhi[t] = 0.0f; }
-        auto tensor_of = [](int o) {      // packed offset -> 0 A_diag, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e
-            if (o < Lt::O_A) return 2;
-            if (o < Lt::O_NU) {
-                const int t = o - Lt::O_A;
-                int l = 0;
-                while ((l + 1) * (l + 2) / 2 <= t) ++l;
-                return (t - l * (l + 1) / 2 == l) ? 0 : 1;
-            }
-            return (o < Lt::O_GA) ? 3 : 4;
-        };
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int o = Lt::O_MU; o < Lt::PK; ++o) {
-                const int j = k * Lt::PK + o;
-                const int t = tensor_of(o);
-                if (t == 2 && !kc.q_musx) continue;
-                const FqRange& r = (t == 0) ? br.ad : ((t == 1) ? br.ac : ((t == 2) ? br.mu : ((t == 3) ? br.nu : br.ga)));
-                const float x = Praw[j], v = x - r.back;
-                const bool below = !r.zero && (v < r.nmin), above = !r.zero && (v > r.nmax);
-                GL[t] += below ? acc[j] : 0.0f;
-                GA[t] += above ? acc[j] : 0.0f;
-                nlo[t] += (keep[k] && x == br.lo[t]) ? 1.0f : 0.0f;
-                nhi[t] += (keep[k] && x == br.hi[t]) ? 1.0f : 0.0f;
-                acc[j] = (below || above) ? 0.0f : acc[j];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            GL[t] = GL[t] / fmaxf(nlo[t], 1.0f);
-            GA[t] = GA[t] / fmaxf(nhi[t], 1.0f);
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-#pragma unroll
-            for (int o = Lt::O_MU; o < Lt::PK; ++o) {
-                const int j = k * Lt::PK + o;
-                const int t = tensor_of(o);
-                if (t == 2 && !kc.q_musx) continue;
-                const float x = Praw[j];
-                acc[j] += (keep[k] && x == br.lo[t]) ? GL[t] : 0.0f;
-                acc[j] += (keep[k] && x == br.hi[t]) ? GA[t] : 0.0f;
-            }
         }
     }
 }
@@ -696,18 +631,26 @@ struct Tile {
     __host__ __device__ static int off_scratch(int N, int CR) { return off_mv(N, CR) + NB * MV_STRIDE; }
     __host__ __device__ static int off_tgt(int N, int CR) { return off_scratch(N, CR) + WAVES * CH * ROW; }
     __host__ __device__ static int off_lw(int N, int CR) { return off_tgt(N, CR) + NB * C * N; }
-    __host__ __device__ static size_t bytes(int N, bool has_lw, int CR = D) {
-        return sizeof(float) * (size_t)(off_lw(N, CR) + (has_lw ? NB * N : 0));
+    // hq: the quantised image is only carved out when the graph is fake-quantised (fit kernels)
+    __host__ __device__ static size_t bytes(int N, bool has_lw, int CR = D, bool hq = false) {
+        return sizeof(float) * (size_t)off_ssim(N, has_lw, CR, hq);
     }
+    // fake-quantised graph (quantize_pis / quantization_mode 2, 3): per block a second parameter image holding the
+    // quantised values the forward / backward read (written by the slot owners after every Adam step), the five
+    // mode-3 range records (8 floats each) and a 12-float hand-off area of the block-wide all-reduce
+    static constexpr int QI_RNG = 40;
+    static constexpr int QI_OUT = 12;
+    static constexpr int QI_STRIDE = round_up(Lt::LP_STRIDE + QI_RNG + QI_OUT, 4);
+    __host__ __device__ static int off_qimg(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * N : 0), 4); }
     // ssim_opt (G == 64, one block per wavefront): the two tap tables of the workgroup, then per wavefront
     // the planes X [C][N] (quantised reconstruction -> dL/dq), Wa [5][N] (column sums of x, x^2, xy, y, y^2;
     // later the row pass of the adjoint) and Wb [3][N] (coefficient maps)
-    __host__ __device__ static int off_ssim(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * N : 0), 4); }
+    __host__ __device__ static int off_ssim(int N, bool has_lw, int CR, bool hq = false) { return off_qimg(N, has_lw, CR) + (hq ? NB * QI_STRIDE : 0); }
     // G == 16 (16x16 blocks only): the SSIM stage runs in registers (ssim_block16), LDS holds just X per block
     __host__ __device__ static int ssim_tabs(int bh, int bw) { return (G == 16) ? 0 : round_up(11 * (bh + bw), 4); }
     __host__ __device__ static int ssim_wave(int N) { return (G == 16) ? BPW * C * N : round_up(C * N + 8 * N, 4); }
-    __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw) {
-        return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR) + ssim_tabs(bh, bw) + WAVES * ssim_wave(N));
+    __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw, bool hq = false) {
+        return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR, hq) + ssim_tabs(bh, bw) + WAVES * ssim_wave(N));
     }
 };
 
@@ -908,6 +851,32 @@ __device__ __forceinline__ float ssim_block16(float* __restrict__ X, const float
     return part;
 }
 
+// All-reduce of ten per-lane values over the G lanes of a block (sum, or min with MIN) through the wavefront's
+// reduction scratch: every lane stores its ten values as rows, lane `sub` < 10 folds row `sub` over the block's
+// lanes in a fixed order and publishes the result in s_out, every lane reads the ten results back.
+template <int G, int ROW, bool MIN>
+__device__ __forceinline__ void block_allreduce10(float (&v)[10], float* __restrict__ scratch_wave, float* __restrict__ s_out,
+                                                  int lane, int grp, int sub) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) scratch_wave[i * ROW + lane] = v[i];
+    wave_lds_sync();
+    if (sub < 10) {
+        const float4* row = reinterpret_cast<const float4*>(scratch_wave + sub * ROW + grp * G);
+        float4 r = row[0];
+#pragma unroll
+        for (int i = 1; i < G / 4; ++i) {
+            const float4 q = row[i];
+            if (MIN) { r.x = fminf(r.x, q.x); r.y = fminf(r.y, q.y); r.z = fminf(r.z, q.z); r.w = fminf(r.w, q.w); }
+            else { r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w; }
+        }
+        s_out[sub] = MIN ? fminf(fminf(r.x, r.y), fminf(r.z, r.w)) : (r.x + r.y) + (r.z + r.w);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 10; ++i) v[i] = s_out[i];
+    wave_lds_sync();
+}
+
 // ---------------------------------------------------------------------------
 // fit kernel: n_iters x (forward + backward + prune + TF1 Adam), parameters resident
 // ---------------------------------------------------------------------------
@@ -968,8 +937,12 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     const bool has_lw = a.loss_w != nullptr;
 
     stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    // fake-quantised graph: the quantised parameter image of the block, its mode-3 range records, all-reduce hand-off
+    float* s_q = lds + T::off_qimg(N, has_lw, CR) + lb * T::QI_STRIDE;
+    float* s_rng = s_q + Lt::LP_STRIDE;
+    float* s_out = s_rng + T::QI_RNG;
     // ssim_opt planes (see Tile::off_ssim)
-    float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
+    float* s_ssim = lds + T::off_ssim(N, has_lw, CR, (a.kc.qmode != 0) || (a.kc.qpis != 0));
     const int bh = a.bh, bw = a.bw;
     const float* s_Tr = s_ssim;
     const float* s_Tc = s_ssim + bh * 11;
@@ -994,12 +967,17 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     // ---- owner set-up: this lane owns packed slots sub, sub+G, ... of its block --------
     // per-slot learning rate (0 = not trained) and l1 regulariser constant stay in registers;
     // the parameter and its Adam slots live in LDS between iterations.
-    float lr[T::SPL], reg[T::SPL], qlo[T::SPL], qhi[T::SPL];
+    // fixed-range fake quant of the slot (pis; everything in mode 2): nudged range + step; qt[s] = index of the slot's
+    // mode-3 tensor (0 A_diagonal, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e; -1 none), qk[s] = its kernel
+    float lr[T::SPL], reg[T::SPL], qlo[T::SPL], qhi[T::SPL], qsc[T::SPL], qiv[T::SPL];
+    int qt[T::SPL], qk[T::SPL];
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
         const int j = sub + s * G;
         lr[s] = reg[s] = 0.0f;
         qlo[s] = -__builtin_huge_valf(); qhi[s] = __builtin_huge_valf();
+        qsc[s] = qiv[s] = 0.0f;
+        qt[s] = -1; qk[s] = 0;
         if (j < Lt::NPAR) {
             int tensor, kern; long off;
             decode_slot<D, C, K>(j, b, tensor, off, kern);
@@ -1018,7 +996,12 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? (a.kc.radial ? a.reg_u * (float)D : a.reg_u) : 0.0f);
             // fixed-range fake quant of this variable: the gradient passes inside the nudged range only
             const int qg = (tensor == 0) ? 3 : ((tensor == 1) ? 1 : ((tensor == 4) ? 4 : ((tensor == 5) ? 2 : 0)));
-            if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) { qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; }
+            if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) {
+                qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; qsc[s] = a.kc.q_scale[qg]; qiv[s] = a.kc.q_inv[qg];
+            }
+            qk[s] = kern;
+            if (QUANT && a.kc.qmode == 3 && tensor != 0 && !(tensor == 1 && !a.kc.q_musx))
+                qt[s] = (tensor == 2) ? 0 : ((tensor == 3) ? 1 : ((tensor == 1) ? 2 : ((tensor == 5) ? 3 : 4)));
         } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
             const int k = j - Lt::S_CNT;
             s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
@@ -1033,6 +1016,82 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     float last_loss = 0.0f, last_sse = 0.0f;
     __syncthreads();
 
+    // ---- fake-quantised graph: (re)build the block's quantised image from the raw parameters in s_par.  Runs once here
+    // and after every Adam step; the forward / backward then read s_q and never quantise themselves.  Mode 3: the ranges
+    // are the min / max over the kernels with qpis > 0 (smoe.py:497-530), found with one block-wide all-reduce; lane
+    // t < 5 nudges range t (TF Nudge()) and publishes it; every owner quantises its own slots.
+    auto pick5 = [](const float (&v)[10], int base, int t) {
+        return (t == 0) ? v[base] : ((t == 1) ? v[base + 1] : ((t == 2) ? v[base + 2] : ((t == 3) ? v[base + 3] : v[base + 4])));
+    };
+    auto refresh_quantised_image = [&]() {
+        if constexpr (QUANT) {
+            if (a.kc.qmode == 3) {
+                constexpr float INF = __builtin_huge_valf();
+                float ex[10];                              // lo[0..4], -hi[5..9] of this lane's slots
+#pragma unroll
+                for (int i = 0; i < 10; ++i) ex[i] = INF;
+                const FqRange rp = fq_fixed(a.kc, 3);
+#pragma unroll
+                for (int s = 0; s < T::SPL; ++s) {
+                    const int j = sub + s * G;
+                    if (j < Lt::NPAR && qt[s] >= 0) {
+                        const bool keep = fq_val(s_par[qk[s] * Lt::PK + Lt::O_PI], rp) > 0.0f;      // pis_mask = qpis > 0
+                        const float x = s_par[j];
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) {
+                            const bool hit = keep && (qt[s] == t);
+                            ex[t] = hit ? fminf(ex[t], x) : ex[t];
+                            ex[5 + t] = hit ? fminf(ex[5 + t], -x) : ex[5 + t];
+                        }
+                    }
+                }
+                block_allreduce10<G, T::ROW, true>(ex, s_scratch, s_out, lane, grp, sub);
+                {
+                    const int t = min(sub, 4);
+                    float lo = pick5(ex, 0, t), hi = -pick5(ex, 5, t);
+                    if (lo == INF) { lo = 0.0f; hi = 0.0f; }                       // no kernel left
+                    if (t == 1) { lo = fminf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }    // structural zeros of the A_corr variable
+                    const float lv = (t < 2) ? a.kc.q_levels[0] : ((t == 2) ? a.kc.q_levels[1] : ((t == 3) ? a.kc.q_levels[2] : a.kc.q_levels[4]));
+                    const FqRange r = fq_vars(lo, hi, lv, t == 0 || t == 3);
+                    if (sub < 5) {
+                        float* o = s_rng + t * 8;
+                        o[0] = r.nmin; o[1] = r.nmax; o[2] = r.scale; o[3] = r.inv;
+                        o[4] = r.back; o[5] = r.zero ? 1.0f : 0.0f; o[6] = lo; o[7] = hi;
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            if (j < Lt::NPAR) {
+                const float x = s_par[j];
+                float q = x;
+                if (qsc[s] != 0.0f) {                       // fixed range (pis; mode 2)
+                    const float cl = fminf(fmaxf(x, qlo[s]), qhi[s]);
+                    q = floorf((cl - qlo[s]) * qiv[s] + 0.5f) * qsc[s] + qlo[s];
+                }
+                if constexpr (QUANT) {
+                    if (qt[s] >= 0) {
+                        const float* o = s_rng + qt[s] * 8;
+                        FqRange r;
+                        r.nmin = o[0]; r.nmax = o[1]; r.scale = o[2]; r.inv = o[3]; r.back = o[4]; r.zero = o[5] != 0.0f;
+                        q = fq_val(x, r);
+                    }
+                }
+                s_q[j] = q;
+            } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+                s_q[Lt::LP_ACT + (j - Lt::S_CNT)] = s_par[Lt::LP_ACT + (j - Lt::S_CNT)];
+            } else if (j == Lt::S_LOSS) {
+                s_q[Lt::LP_FROZEN] = s_par[Lt::LP_FROZEN];
+            }
+        }
+        wave_lds_sync();
+    };
+    if (has_quant) refresh_quantised_image();
+    const float* s_img = has_quant ? s_q : s_par;      // what the graph is built on
+
     float b1p = a.b1p, b2p = a.b2p;
     const KernelConsts kc = a.kc;
     const float beta1 = a.beta1, beta2 = a.beta2, adam_eps = a.eps, clip = a.clip;
@@ -1046,8 +1105,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         float reg_loss = 0.0f;
         {
             BlockRegs<D, C, K> R;
-            R.load(s_par);
-            if (has_quant) quantize_packed<D, C, K, QUANT>(R.P, kc);     // the graph sees the fake-quantised variables
+            R.load(s_img);                                  // the graph sees the fake-quantised variables
             R.template derive<IC>(kc);
             frozen = R.frozen();
             if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
@@ -1104,14 +1162,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         }
         {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
-            R2.load(s_par);
-            if (has_quant) quantize_packed<D, C, K, QUANT>(R2.P, kc);
+            R2.load(s_img);
             finish_partials<D, C, K, IC>(R2, kc, acc);
-        }
-        if constexpr (QUANT) if (kc.qmode == 3) {            // back through fake_quant_with_min_max_vars
-            BlockRegs<D, C, K> R3;
-            R3.load(s_par);
-            route_quant_partials<D, C, K>(R3.P, kc, acc);
         }
 
         float total[T::SPL];
@@ -1119,6 +1171,73 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 
         // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
         const float bias = sqrtf(1.0f - b2p) / (1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
+        // gradients w.r.t. the (quantised) graph variables incl. the l1 terms
+        float gq[T::SPL];
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = sub + s * G;
+            const int jc = (j < Lt::NPAR) ? j : 0;
+            float gsum = total[s];
+            if (has_reg && reg[s] != 0.0f) {
+                const int k = jc / Lt::PK;
+                const float piv = s_img[k * Lt::PK + Lt::O_PI];
+                const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (piv > 0.0f);
+                float rs = reg[s];
+                if (kc.kcount_norm && (jc - k * Lt::PK) == Lt::O_PI) {          // pis_l1 / count(qpis > 0), smoe.py:1022-1027
+                    float cnt = 0.0f;
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) cnt += (s_img[kk * Lt::PK + Lt::O_PI] > 0.0f) ? 1.0f : 0.0f;
+                    rs = kc.pis_l1_raw / fmaxf(cnt, 1.0f);
+                }
+                gsum += act ? rs : 0.0f;
+            }
+            gq[s] = gsum;
+        }
+        if constexpr (QUANT) {
+            if (kc.qmode == 3) {
+                // back through fake_quant_with_min_max_vars (+ reduce_min / reduce_max): inside the nudged range the
+                // gradient passes; what falls below / above goes to the extreme elements of the tensor, split over ties
+                float rs[10], cn[10];                      // GL[0..4] GA[5..9] ; tie counts at lo / hi
+                bool bel[T::SPL], abv[T::SPL], tlo[T::SPL], thi[T::SPL];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) { rs[i] = 0.0f; cn[i] = 0.0f; }
+                const FqRange rp = fq_fixed(kc, 3);
+#pragma unroll
+                for (int s = 0; s < T::SPL; ++s) {
+                    const int j = sub + s * G;
+                    bel[s] = abv[s] = tlo[s] = thi[s] = false;
+                    if (j < Lt::NPAR && qt[s] >= 0) {
+                        const float* o = s_rng + qt[s] * 8;
+                        const float x = s_par[j], v = x - o[4];
+                        const bool zero = o[5] != 0.0f;
+                        const bool keep = fq_val(s_par[qk[s] * Lt::PK + Lt::O_PI], rp) > 0.0f;
+                        bel[s] = !zero && (v < o[0]);
+                        abv[s] = !zero && (v > o[1]);
+                        tlo[s] = keep && (x == o[6]);
+                        thi[s] = keep && (x == o[7]);
+#pragma unroll
+                        for (int t = 0; t < 5; ++t) {
+                            const bool hit = qt[s] == t;
+                            rs[t] += (hit && bel[s]) ? gq[s] : 0.0f;
+                            rs[5 + t] += (hit && abv[s]) ? gq[s] : 0.0f;
+                            cn[t] += (hit && tlo[s]) ? 1.0f : 0.0f;
+                            cn[5 + t] += (hit && thi[s]) ? 1.0f : 0.0f;
+                        }
+                    }
+                }
+                block_allreduce10<G, T::ROW, false>(rs, s_scratch, s_out, lane, grp, sub);
+                block_allreduce10<G, T::ROW, false>(cn, s_scratch, s_out, lane, grp, sub);
+#pragma unroll
+                for (int s = 0; s < T::SPL; ++s) {
+                    if (qt[s] >= 0) {
+                        float g = (bel[s] || abv[s]) ? 0.0f : gq[s];
+                        g += tlo[s] ? pick5(rs, 0, qt[s]) / fmaxf(pick5(cn, 0, qt[s]), 1.0f) : 0.0f;
+                        g += thi[s] ? pick5(rs, 5, qt[s]) / fmaxf(pick5(cn, 5, qt[s]), 1.0f) : 0.0f;
+                        gq[s] = g;
+                    }
+                }
+            }
+        }
         float newp[T::SPL];
         bool bad = false;
 #pragma unroll
@@ -1128,25 +1247,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             const float pv = s_par[jc];
             const float mv = s_mv[2 * jc];
             const float vv = s_mv[2 * jc + 1];
-            float gsum = total[s];
-            if (has_reg && reg[s] != 0.0f) {
-                const int k = jc / Lt::PK;
-                float piv = s_par[k * Lt::PK + Lt::O_PI];
-                if (kc.qpis) piv = fq_val(piv, fq_fixed(kc, 3));
-                const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (piv > 0.0f);
-                float rs = reg[s];
-                if (kc.kcount_norm && (jc - k * Lt::PK) == Lt::O_PI) {          // pis_l1 / count(qpis > 0), smoe.py:1022-1027
-                    float cnt = 0.0f;
-#pragma unroll
-                    for (int kk = 0; kk < K; ++kk) {
-                        float pk = s_par[kk * Lt::PK + Lt::O_PI];
-                        if (kc.qpis) pk = fq_val(pk, fq_fixed(kc, 3));
-                        cnt += (pk > 0.0f) ? 1.0f : 0.0f;
-                    }
-                    rs = kc.pis_l1_raw / fmaxf(cnt, 1.0f);
-                }
-                gsum += act ? rs : 0.0f;
-            }
+            float gsum = gq[s];
             gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;     // fixed-range fake quant: straight-through inside
             if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
             const float alpha = lr[s] * bias;
@@ -1176,6 +1277,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             }
         }
         wave_lds_sync();
+        if (has_quant) refresh_quantised_image();
         b1p *= beta1;
         b2p *= beta2;
     }
@@ -1446,7 +1548,7 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     int hl = 0;
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, (a.kc.qmode != 0) || (a.kc.qpis != 0));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1478,7 +1580,7 @@ hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
         kern = ic ? fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true, true> : fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true>;
         hl = 2;
     }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, (a.kc.qmode != 0) || (a.kc.qpis != 0));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1507,7 +1609,7 @@ hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
     int hl = 0;
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, false, true>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, false, true>; hl = 2; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, (a.kc.qmode != 0) || (a.kc.qpis != 0));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1537,7 +1639,7 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
         auto kern = ic ? fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true, false, true> : fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
         int hl = (G == 16) ? 1 : 0;
         if (hoist >= 1) { kern = ic ? fit_kernel<D, C, K, G, WAVES, 1, true, false, true> : fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
-        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw);
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, (a.kc.qmode != 0) || (a.kc.qpis != 0));
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1566,12 +1668,12 @@ hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
 }
 
 template <int D, int C, int K, int G, int WAVES>
-size_t lds_bytes(int N, bool has_lw) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw); }
+size_t lds_bytes(int N, bool has_lw, bool hq) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw, D, hq); }
 
 template <int D, int C, int K, int G, int WAVES>
-size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw) {
+size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw, bool hq) {
     if (D != 2 || (G == 16 && (bh != 16 || bw != 16))) return (size_t)-1;
-    return Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw);
+    return Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw, hq);
 }
 
 template <int D, int C, int K, int G, int WAVES>

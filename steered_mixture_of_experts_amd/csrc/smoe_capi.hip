@@ -124,6 +124,7 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
     // pixels per lane, and with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
     int want = h->force_g ? h->force_g : ((num_blocks >= 8192 && h->N <= 512) ? 16 : 64);
     const smoe::Variant* fallback = nullptr;
+    const bool hq = h->cfg.quantization_mode >= 2 || h->cfg.quantize_pis;     // the fit kernels then keep a quantised image in LDS
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels) continue;
         if (h->cfg.ssim_opt) {
@@ -132,10 +133,10 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
             const bool b16 = h->cfg.block_shape[0] == 16 && h->cfg.block_shape[1] == 16;
             const int g = h->force_g ? h->force_g : (b16 ? 16 : 64);
             if (v[i].G != g) continue;
-            if (v[i].lds_bytes_ssim(h->N, has_lw, h->cfg.block_shape[0], h->cfg.block_shape[1]) > 160u * 1024u) continue;
+            if (v[i].lds_bytes_ssim(h->N, has_lw, h->cfg.block_shape[0], h->cfg.block_shape[1], hq) > 160u * 1024u) continue;
             return &v[i];
         }
-        if (v[i].lds_bytes(h->N, has_lw) > 160u * 1024u) continue;
+        if (v[i].lds_bytes(h->N, has_lw, hq) > 160u * 1024u) continue;
         if (v[i].G == want) return &v[i];
         if (!fallback) fallback = &v[i];
     }

@@ -106,11 +106,11 @@ struct Variant {
     const char* name;
     hipError_t (*fit)(const FitArgs&, int hoist_level, hipStream_t);
     hipError_t (*fwd)(const FwdArgs&, hipStream_t);
-    size_t (*lds_bytes)(int N, bool has_lw);
+    size_t (*lds_bytes)(int N, bool has_lw, bool quant_image);
     int (*fit_waves_per_cu)(int N, bool has_lw);
     hipError_t (*fit_ssim)(const FitArgs&, int hoist_level, hipStream_t);   // ssim_opt (D == 2, G == 64)
     hipError_t (*fwd_ssim)(const FwdArgs&, hipStream_t);
-    size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw);
+    size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw, bool quant_image);
     hipError_t (*readmit_quant)(const ReadmitArgs&, const KernelConsts&, hipStream_t);   // fake-quantised graph
     hipError_t (*fit_quant)(const FitArgs&, int hoist_level, hipStream_t);               // quantization_mode 2 / 3
     hipError_t (*fwd_quant)(const FwdArgs&, hipStream_t);
