@@ -615,9 +615,9 @@ class SharedSmoe:
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
-        if quantization_mode not in (0, 2):
-            raise NotImplementedError("SharedSmoe: quantization_mode 0 and 2 (fixed ranges) are built; mode 1 (quantise at "
-                                      "validation) and mode 3 (image-wide min/max ranges) are not")
+        if quantization_mode not in (0, 1, 2):
+            raise NotImplementedError("SharedSmoe: quantization_mode 0, 1 (quantise at validation) and 2 (fixed ranges) are "
+                                      "built; mode 3 (image-wide min/max ranges) is not")
         assert kernels_per_dim is not None or init_params is not None, \
             "You need to specify the kernel grid size or give initial parameters."
         image = np.asarray(image, dtype=np.float32)
@@ -697,6 +697,11 @@ class SharedSmoe:
         self.iter = iter_offset
         self.valid = False
         self.reconstruction_image = self.weight_matrix_argmax = None
+        self.qparams = self.rparams = None                                # quantizer.py products (leading axis 1 = the model)
+        self.qreconstruction_image = None
+        self.qvalid = False
+        self.qlosses, self.qmses = [], []
+        self.best_qloss, self.best_qmse = None, []
 
     def _make_engine(self, pis_l1, u_l1):
         from .engine import SharedConfig
@@ -746,14 +751,35 @@ class SharedSmoe:
             pis = _fake_quant_fixed(pis, self.lower_bounds[3], self.upper_bounds[3], self.bit_depths[3])
         return loss_val, mse_val, int((pis > 0).sum().item())
 
-    def run_batched(self, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, train=True, update_reconstruction=False, **kw):
+    def _quantize(self):
+        """quantize_params + rescaler (quantizer.py:4-145) on the global kernel set (one model = leading axis 1)."""
+        from .quantizer import quantize_params, rescaler
+        self.qparams = quantize_params(self, {k: v[None] for k, v in self.get_params().items()})
+        if self.quantization_mode == 1:
+            self.rparams = rescaler(self, self.qparams)
+
+    def run_batched(self, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, train=True, update_reconstruction=False,
+                    with_quantized_params=False, **kw):
         for name, val in kw.items():
             if val not in (False, None, 100):
                 raise NotImplementedError(f"run_batched({name}=...) is outside the hot path")
-        self.valid = False
         self._make_engine(pis_l1, u_l1)
         eng, nb = self._engine, self.hi - self.lo
         dev = eng.device
+        if with_quantized_params:                                         # smoe.py:1688-1689: the lists are not touched
+            assert self.rparams is not None, "quantize_params + rescaler first (smoe.py:1499-1501)"
+            self.qvalid = False
+            rp = {k: torch.from_numpy(np.ascontiguousarray(self.rparams[k][0], dtype=np.float32)).to(dev) for k in PARAM_NAMES}
+            out = eng.forward(self._target, rp, self._lists, first_batch=self.lo, want_recon=update_reconstruction,
+                              want_argmax=False, update_lists=False)
+            if update_reconstruction:
+                bs, d = self.batch_size_valued, self.dim_domain
+                rec = sdist.allgather_blocks(blk.from_planar(out["recon"].cpu().numpy(), bs), self.num_batches)
+                self.qreconstruction_image = blk.blocks_to_image(rec, self.image.shape[:d], bs)
+                self.qvalid = True
+            loss_val, mse_val, num_pi = self._global(out["loss"], out["sse"])
+            return loss_val, mse_val, num_pi, 0
+        self.valid = False
         if train:
             assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
             loss = torch.zeros((nb,), dtype=torch.float32, device=dev)
@@ -784,6 +810,13 @@ class SharedSmoe:
         if optimizer1:
             self.set_optimizer(optimizer1, optimizer2, optimizer3, grad_clip_value_abs=grad_clip_value_abs)
         assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
+        if self.quantization_mode >= 1:                                   # smoe.py:1498-1505
+            self._quantize()
+        if self.quantization_mode == 1:
+            self.best_qloss, self.best_qmse, _, _ = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False,
+                                                                     update_reconstruction=True, with_quantized_params=True)
+            self.qlosses.append((0, self.best_qloss))
+            self.qmses.append((0, self.best_qmse))
         self.best_loss, self.best_mse, num_pi, num_sv = self.run_batched(
             pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
         self.losses.append((self.iter, self.best_loss))
@@ -815,6 +848,13 @@ class SharedSmoe:
                 if not validate:
                     loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
             if validate:
+                if self.quantization_mode >= 1:                               # smoe.py:1539-1545,1585-1587
+                    self._quantize()
+                if self.quantization_mode == 1:
+                    qloss_val, qmse_val, _, _ = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False,
+                                                                 update_reconstruction=True, with_quantized_params=True)
+                    self.qlosses.append((i, qloss_val))
+                    self.qmses.append((i, qmse_val))
                 loss_val, mse_val, num_pi, num_sv = self.run_batched(
                     pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
                 if np.isnan(loss_val) or loss_val + 1 > (self.losses[0][1] + 100) * 10:   # smoe.py:1565-1570
@@ -861,6 +901,17 @@ class SharedSmoe:
         if not self.valid:
             self.run_batched(train=False, update_reconstruction=True)
         return self.weight_matrix_argmax
+
+    def get_qreconstruction(self):
+        if not self.qvalid:
+            self.run_batched(train=False, update_reconstruction=True, with_quantized_params=True)
+        return self.qreconstruction_image
+
+    def get_qlosses(self):
+        return self.qlosses
+
+    def get_qmses(self):
+        return self.qmses
 
     def get_psnr(self):
         rec = self.get_reconstruction()
