@@ -174,6 +174,46 @@ def test_block_independence_determinism_idempotence_at_full_size():
     eng.close()
 
 
+@pytest.mark.parametrize("kw", [{"ssim_opt": True}, {"quantization_mode": 3, "quantize_pis": True, "bit_depths": (14, 12, 8, 10, 10)},
+                                {"quantization_mode": 2, "quantize_pis": True, "bit_depths": (16, 14, 8, 10, 10),
+                                 "lower_bounds": (-200, -.3, -1, 0, -4), "upper_bounds": (200, 1.3, 2, 2, 4)},
+                                {"train_inverse_cov": True}, {"radial_as": True}],
+                         ids=["ssim", "quant3", "quant2", "invcov", "radial"])
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_variant_kernels_keep_blocks_independent_at_full_size(kw, tiling):
+    """The SSIM planes, the quantised LDS image with its block-wide all-reduces, the inverse-covariance and radial
+    variants: a block's fit inside the 65 536-block bench batch is bit-identical to the same block fitted in a ragged
+    150-block slice, and two runs agree bit for bit."""
+    B, shape, C, kpd, K = 65536, (16, 16), 1, [2, 2], 4
+    b = blk.synthetic_blocks(B, shape, C, 20260002)
+    T = torch.from_numpy(blk.to_planar(b)).cuda()
+    p0 = blk.init_block_params(b, kpd, True, kw.get("train_inverse_cov", False))
+    eng = _engine(shape, C, K, lr_steer=0.05, **kw)
+    eng.set_tiling(tiling)
+
+    def run(Tsub, psub, n):
+        dp = _dev(psub)
+        st = eng.new_adam_state(dp)
+        act = torch.full((Tsub.shape[0],), 15, dtype=torch.int32, device="cuda")
+        eng.forward(Tsub, dp, act, want_recon=False)
+        eng.fit(Tsub, dp, st, act, n)
+        eng.update_kernel_list(dp, act)
+        out = eng.forward(Tsub, dp, act, want_recon=True, update_active=False)
+        return {k: v.cpu().numpy() for k, v in dp.items()}, out["recon"].cpu().numpy(), out["loss"].cpu().numpy()
+
+    full, rec_full, loss_full = run(T, p0, 8)
+    again, rec_again, _ = run(T, p0, 8)
+    for k in full:
+        assert np.array_equal(full[k], again[k]), k
+    lo, hi = 40000, 40150
+    sub, rec_sub, loss_sub = run(T[lo:hi].contiguous(), {k: v[lo:hi] for k, v in p0.items()}, 8)
+    for k in full:
+        assert np.array_equal(full[k][lo:hi], sub[k]), k
+    assert np.array_equal(rec_full[lo:hi], rec_sub) and np.array_equal(loss_full[lo:hi], loss_sub)
+    assert np.isfinite(full["nu_e"]).all() and np.isfinite(loss_full).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("name,img_shape,bs,C,kpd,n_iters", [
     ("cfg3", (1080, 1920), (32, 32), 3, [2, 4], 3),
     ("cfg4", (2160, 3840), (16, 16), 3, [2, 2], 3),
