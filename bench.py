@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--kernels-per-dim", type=int, nargs="+", default=[2, 2])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quantize-pis", action="store_true",
+                    help="diagnostic: run the constructor default (pis not fake-quantised) instead of the CLI default")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary single-image measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
@@ -117,7 +119,8 @@ def main():
     blocks_np = blk.synthetic_blocks(B, shape, C, 20260002 + rank)
     params_np = blk.init_block_params(blocks_np, kpd)
     # CLI defaults (smoe_test.py:262-352): -qp/--quantize_pis defaults to True, so the graph fake-quantises the pis
-    eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv, quantize_pis=True))
+    eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv,
+                                   quantize_pis=not args.no_quantize_pis))
     if args.tiling:
         eng.set_tiling(args.tiling)
     dev = eng.device

@@ -53,10 +53,11 @@ struct Layout {
     static constexpr int S_SSE = NPAR + 1;
     static constexpr int S_CNT = NPAR + 2;
     static constexpr int NSLOT = NPAR + 2 + K;
-    // LDS image of one block: packed params, K active flags, frozen flag
+    // LDS image of one block: packed params, K active flags, frozen flag, K fake-quantised pis (quantize_pis)
     static constexpr int LP_ACT = NPAR;
     static constexpr int LP_FROZEN = NPAR + K;
-    static constexpr int LP_STRIDE = round_up(NPAR + K + 1, 4);
+    static constexpr int LP_QPI = NPAR + K + 1;
+    static constexpr int LP_STRIDE = round_up(NPAR + 2 * K + 1, 4);
 };
 
 // Where packed parameter j of block b lives in the reference's tensors
@@ -490,8 +491,8 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
             }
         } else {
 #pragma unroll
-        for (int m = 0; m < D; ++m) {
-            const float uz = u * z[k][m];
+        for (int m = 0; m < D - HL; ++m) {                 // z'_m is a lane constant for m >= D-HL: sum u z'_m = z'_m sum u,
+            const float uz = u * z[k][m];                  // completed after the loop (complete_const)
             a[Lt::O_MU + m] += uz;
 #pragma unroll
             for (int l = m; l < D - HL; ++l)               // hoisted rows l >= D-HL are x_l * sum(uz), done after the loop
@@ -516,6 +517,10 @@ __device__ __forceinline__ void complete_const(const BlockRegs<D, C, K>& R, cons
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float* a = acc + k * Lt::PK;
+        if (!IC) {          // z'_m (m >= D-HL) depends on hoisted coordinates only: it is R.hz[k][m] for every pixel of the lane
+#pragma unroll
+            for (int m = D - HL; m < D; ++m) a[Lt::O_MU + m] = R.hz[k][m] * a[Lt::O_PI];
+        }
 #pragma unroll
         for (int l = D - HL; l < D; ++l) {
             if (IC) {       // sum u r_l = r_l sum u ; sum u r_l r_m = r_l sum u r_m (m not hoisted) = r_l r_m sum u (m hoisted)
@@ -942,7 +947,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     float* s_rng = s_q + Lt::LP_STRIDE;
     float* s_out = s_rng + T::QI_RNG;
     // ssim_opt planes (see Tile::off_ssim)
-    float* s_ssim = lds + T::off_ssim(N, has_lw, CR, (a.kc.qmode != 0) || (a.kc.qpis != 0));
+    float* s_ssim = lds + T::off_ssim(N, has_lw, CR, QUANT);
     const int bh = a.bh, bw = a.bw;
     const float* s_Tr = s_ssim;
     const float* s_Tc = s_ssim + bh * 11;
@@ -1062,6 +1067,20 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 wave_lds_sync();
             }
         }
+        if constexpr (!QUANT) {
+            // quantize_pis alone (the CLI default): the K quantised pis live in K extra floats of the block's image
+#pragma unroll
+            for (int s = 0; s < T::SPL; ++s) {
+                const int j = sub + s * G;
+                if (j < Lt::NPAR && qsc[s] != 0.0f) {
+                    const float x = s_par[j];
+                    const float cl = fminf(fmaxf(x, qlo[s]), qhi[s]);
+                    s_par[Lt::LP_QPI + qk[s]] = floorf((cl - qlo[s]) * qiv[s] + 0.5f) * qsc[s] + qlo[s];
+                }
+            }
+            wave_lds_sync();
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = sub + s * G;
@@ -1090,7 +1109,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         wave_lds_sync();
     };
     if (has_quant) refresh_quantised_image();
-    const float* s_img = has_quant ? s_q : s_par;      // what the graph is built on
+    const float* s_img = (QUANT && has_quant) ? s_q : s_par;      // what the graph is built on (QUANT: the quantised image)
+    const bool patch_pis = !QUANT && (a.kc.qpis != 0);               // default kernels: quantised pis from the K extra floats
 
     float b1p = a.b1p, b2p = a.b2p;
     const KernelConsts kc = a.kc;
@@ -1106,6 +1126,10 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         {
             BlockRegs<D, C, K> R;
             R.load(s_img);                                  // the graph sees the fake-quantised variables
+            if (patch_pis) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) R.P[k * Lt::PK + Lt::O_PI] = R.P[Lt::LP_QPI + k];
+            }
             R.template derive<IC>(kc);
             frozen = R.frozen();
             if (has_reg) {                                  // smoe.py:1027,1044 (active kernels only)
@@ -1163,6 +1187,10 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
             R2.load(s_img);
+            if (patch_pis) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) R2.P[k * Lt::PK + Lt::O_PI] = R2.P[Lt::LP_QPI + k];
+            }
             finish_partials<D, C, K, IC>(R2, kc, acc);
         }
 
@@ -1180,13 +1208,13 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             float gsum = total[s];
             if (has_reg && reg[s] != 0.0f) {
                 const int k = jc / Lt::PK;
-                const float piv = s_img[k * Lt::PK + Lt::O_PI];
+                const float piv = patch_pis ? s_par[Lt::LP_QPI + k] : s_img[k * Lt::PK + Lt::O_PI];
                 const bool act = (s_par[Lt::LP_ACT + k] != 0.0f) && (piv > 0.0f);
                 float rs = reg[s];
                 if (kc.kcount_norm && (jc - k * Lt::PK) == Lt::O_PI) {          // pis_l1 / count(qpis > 0), smoe.py:1022-1027
                     float cnt = 0.0f;
 #pragma unroll
-                    for (int kk = 0; kk < K; ++kk) cnt += (s_img[kk * Lt::PK + Lt::O_PI] > 0.0f) ? 1.0f : 0.0f;
+                    for (int kk = 0; kk < K; ++kk) cnt += ((patch_pis ? s_par[Lt::LP_QPI + kk] : s_img[kk * Lt::PK + Lt::O_PI]) > 0.0f) ? 1.0f : 0.0f;
                     rs = kc.pis_l1_raw / fmaxf(cnt, 1.0f);
                 }
                 gsum += act ? rs : 0.0f;
@@ -1548,7 +1576,7 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     int hl = 0;
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, (a.kc.qmode != 0) || (a.kc.qpis != 0));
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, false);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1580,7 +1608,7 @@ hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
         kern = ic ? fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true, true> : fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, true>;
         hl = 2;
     }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, (a.kc.qmode != 0) || (a.kc.qpis != 0));
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, true);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1609,7 +1637,7 @@ hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
     int hl = 0;
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, false, true>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, false, true>; hl = 2; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, (a.kc.qmode != 0) || (a.kc.qpis != 0));
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, false);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1639,7 +1667,7 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
         auto kern = ic ? fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true, false, true> : fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
         int hl = (G == 16) ? 1 : 0;
         if (hoist >= 1) { kern = ic ? fit_kernel<D, C, K, G, WAVES, 1, true, false, true> : fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
-        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, (a.kc.qmode != 0) || (a.kc.qpis != 0));
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, false);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;

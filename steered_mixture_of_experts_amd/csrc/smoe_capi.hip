@@ -124,7 +124,7 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
     // pixels per lane, and with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
     int want = h->force_g ? h->force_g : ((num_blocks >= 8192 && h->N <= 512) ? 16 : 64);
     const smoe::Variant* fallback = nullptr;
-    const bool hq = h->cfg.quantization_mode >= 2 || h->cfg.quantize_pis;     // the fit kernels then keep a quantised image in LDS
+    const bool hq = h->cfg.quantization_mode >= 2;     // the mode-2/3 fit kernels keep a quantised parameter image in LDS
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels) continue;
         if (h->cfg.ssim_opt) {

@@ -89,19 +89,8 @@ def test_facade_on_gpu_matches_facade_on_the_c_oracle():
     assert g.get_num_pis() == c.get_num_pis()
 
 
-def test_cfg2_full_fit_psnr_parity():
-    """BASELINE configs[1]: 512x512 grayscale, 16x16 blocks, K=4, 200 Adam iterations.  The
-    reference's default hyper-parameters make individual trajectories chaotic, so
-    parity is statistical: median block PSNR within 0.05 dB of the CPU restatement; the
-    aggregate PSNR (dominated by a few blown-up blocks) within the restatement's own
-    fp32-vs-fp64 spread."""
-    B, shape, C, kpd, K, n = 1024, (16, 16), 1, [2, 2], 4, 200
-    b = blk.synthetic_blocks(B, shape, C, 20260002)
-    T = blk.to_planar(b)
-    p0 = blk.init_block_params(b, kpd)
-    cfg = o.OracleConfig(block_shape=shape, channels=C, kernels=K)
-    coords = np.ascontiguousarray(o.block_coords(shape).T)
-    # CPU restatement (plain C, fp32): eval, 100, readmit, eval, 100, readmit, eval
+def _cfg2_oracle_run(p0, T, cfg, coords, B, K, n_rounds=2):
+    """CPU restatement (plain C, fp32) of the cfg2 schedule: eval, then n_rounds x (100 iterations, readmit, eval)."""
     pc = {k: v.copy() for k, v in p0.items()}
     m = {k: np.zeros_like(v) for k, v in pc.items()}
     v = {k: np.zeros_like(v) for k, v in pc.items()}
@@ -109,34 +98,78 @@ def test_cfg2_full_fit_psnr_parity():
     f0 = co.forward(cfg, coords, T, pc, bits, want_recon=False, threads=8)
     bp = np.array([cfg.beta1, cfg.beta2], np.float32)
     div = np.zeros(B, np.uint32)
-    for _ in range(2):
+    fc = f0
+    for _ in range(n_rounds):
         co.fit(cfg, coords, T, pc, m, v, bits, 100, bp, diverged=div, loss0=f0["loss"], threads=8)
         mask = ((bits[:, None] >> np.arange(K, dtype=np.uint32)) & 1).astype(bool)
         mask = o.readmit(pc, mask, cfg, np.float32)
         bits[:] = (mask.astype(np.uint32) << np.arange(K, dtype=np.uint32)).sum(axis=1)
         fc = co.forward(cfg, coords, T, pc, bits, want_recon=False, threads=8)
-    # GPU
-    eng = _engine(shape, C, K)
+    return f0, fc, div
+
+
+def _cfg2_gpu_run(p0, T, shape, C, K, B, n_rounds=2, **kw):
+    eng = _engine(shape, C, K, **kw)
     dp = _dev(p0)
     st = eng.new_adam_state(dp)
     Td = torch.from_numpy(T).cuda()
     act = torch.full((B,), 15, dtype=torch.int32, device="cuda")
     dv = torch.zeros((B,), dtype=torch.int32, device="cuda")
     g0 = eng.forward(Td, dp, act, want_recon=False)
-    rel0 = np.abs(g0["loss"].cpu().numpy() - f0["loss"]) / f0["loss"]
-    assert np.quantile(rel0, 0.9) < 2e-5 and rel0.max() < 2e-2          # blocks with a quantiser tie differ by one LSB
-    for _ in range(2):
+    fg = g0
+    for _ in range(n_rounds):
         eng.fit(Td, dp, st, act, 100, diverged=dv, loss0=g0["loss"])
         eng.update_kernel_list(dp, act)
         fg = eng.forward(Td, dp, act, want_recon=False)
-    sse_g, sse_c = fg["sse"].cpu().numpy(), fc["sse"]
-    ps = lambda s: -10 * np.log10(np.maximum(s, 1e-12) / 256)
-    assert abs(np.median(ps(sse_g)) - np.median(ps(sse_c))) < 0.05, (np.median(ps(sse_g)), np.median(ps(sse_c)))
-    assert np.median(ps(sse_g)) > np.median(ps(g0["sse"].cpu().numpy())) + 5.0        # the fit actually fits
-    agg = lambda s: -10 * np.log10(s.sum() / (B * 256))
-    assert abs(agg(sse_g) - agg(sse_c)) < 1.5            # fp32-vs-fp64 spread of the restatement is ~0.3-2.5 dB
-    assert int(dv.sum()) == int(div.sum()) == 0
+    out = (g0["loss"].cpu().numpy(), g0["sse"].cpu().numpy(), fg["sse"].cpu().numpy(), int(dv.sum()))
     eng.close()
+    return out
+
+
+def test_cfg2_full_fit_psnr_parity():
+    """BASELINE configs[1]: 512x512 grayscale, 16x16 blocks, K=4, 200 Adam iterations.
+
+    (a) Well-conditioned run (steering lr = base_lr * 10 instead of the CLI's * 1000): the fit is a deterministic
+        descent and the contract bound holds -- median block PSNR and aggregate PSNR within 0.05 dB of the CPU
+        restatement.
+    (b) CLI-default hyper-parameters: individual trajectories are chaotic.  The statistic's own
+        noise floor is measured here -- the restatement rerun with its parameters perturbed by 1e-7 relative moves
+        the median block PSNR by sigma ~ 0.09 dB (up to 0.15 dB) -- and the GPU has to sit inside that band."""
+    B, shape, C, kpd, K = 1024, (16, 16), 1, [2, 2], 4
+    b = blk.synthetic_blocks(B, shape, C, 20260002)
+    T = blk.to_planar(b)
+    p0 = blk.init_block_params(b, kpd)
+    coords = np.ascontiguousarray(o.block_coords(shape).T)
+    ps = lambda s: -10 * np.log10(np.maximum(s, 1e-12) / 256)
+    agg = lambda s: -10 * np.log10(s.sum() / (B * 256))
+
+    # (a) gentle steering step: tight parity
+    cfg_a = o.OracleConfig(block_shape=shape, channels=C, kernels=K, lr_steer=1e-2)
+    f0, fc, div = _cfg2_oracle_run(p0, T, cfg_a, coords, B, K)
+    l0, sse0, sse_g, ndiv = _cfg2_gpu_run(p0, T, shape, C, K, B, lr_steer=1e-2)
+    rel0 = np.abs(l0 - f0["loss"]) / f0["loss"]
+    assert np.quantile(rel0, 0.9) < 2e-5 and rel0.max() < 2e-2          # blocks with a quantiser tie differ by one LSB
+    assert abs(np.median(ps(sse_g)) - np.median(ps(fc["sse"]))) < 0.05, (np.median(ps(sse_g)), np.median(ps(fc["sse"])))
+    assert abs(agg(sse_g) - agg(fc["sse"])) < 0.05, (agg(sse_g), agg(fc["sse"]))
+    assert np.median(ps(sse_g)) > np.median(ps(sse0)) + 5.0              # the fit actually fits
+    assert ndiv == int(div.sum()) == 0
+
+    # (b) CLI defaults: inside the restatement's own perturbation band
+    cfg_b = o.OracleConfig(block_shape=shape, channels=C, kernels=K)
+    _, fc, div = _cfg2_oracle_run(p0, T, cfg_b, coords, B, K)
+    rng = np.random.default_rng(0)
+    meds = []
+    for _ in range(4):
+        pp = {k: (v * (1 + rng.normal(size=v.shape).astype(np.float32) * 1e-7)).astype(np.float32) for k, v in p0.items()}
+        meds.append(np.median(ps(_cfg2_oracle_run(pp, T, cfg_b, coords, B, K)[1]["sse"])))
+    base = np.median(ps(fc["sse"]))
+    band = max(3 * float(np.std(meds + [base])), float(np.max(np.abs(np.array(meds) - base))), 0.05)
+    _, sse0, sse_g, ndiv = _cfg2_gpu_run(p0, T, shape, C, K, B)
+    assert abs(np.median(ps(sse_g)) - base) <= band, (np.median(ps(sse_g)), base, band)
+    assert band < 0.6                                                    # the band itself is a fraction of a dB
+    assert np.median(ps(sse_g)) > np.median(ps(sse0)) + 5.0
+    assert abs(agg(sse_g) - agg(fc["sse"])) < 1.5            # a few blown-up blocks dominate: fp32-vs-fp64 spread is 0.3-2.5 dB
+    assert ndiv == int(div.sum()) == 0
 
 
 def test_block_independence_determinism_idempotence_at_full_size():
