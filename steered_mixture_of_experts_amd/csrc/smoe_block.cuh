@@ -353,6 +353,7 @@ __device__ __forceinline__ void hoist_const(BlockRegs<D, C, K>& R, const float (
             }
             R.hq[k] = q;
         } else {
+        float q = 0.0f;
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             float h = -R.cz[k][m];
@@ -360,7 +361,9 @@ __device__ __forceinline__ void hoist_const(BlockRegs<D, C, K>& R, const float (
             for (int l = D - 1; l >= D - HL; --l)
                 if (l >= m) h = fmaf(xc[l], R.As[k][tri_index(l, m)], h);
             R.hz[k][m] = h;
+            if (m >= D - HL) q = fmaf(h, h, q);            // z'_m is a lane constant there: its square is pre-summed
         }
+        R.hq[k] = q;
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -415,14 +418,17 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
 #pragma unroll
             for (int l = D - HL; l < D; ++l) z[k][l] = 0.0f;
         } else {
+        maha = (HL > 0) ? R.hq[k] : 0.0f;                 // sum of the squared lane-constant components z'_m, m >= D-HL
 #pragma unroll
-        for (int m = 0; m < D; ++m) {
+        for (int m = 0; m < D - HL; ++m) {
             float zz = (HL > 0) ? R.hz[k][m] : -R.cz[k][m];
 #pragma unroll
             for (int l = D - 1 - HL; l >= m; --l) zz = fmaf(x[l], R.As[k][tri_index(l, m)], zz);
             z[k][m] = zz;
-            maha = (m == 0) ? zz * zz : fmaf(zz, zz, maha);
+            maha = (HL == 0 && m == 0) ? zz * zz : fmaf(zz, zz, maha);
         }
+#pragma unroll
+        for (int m = D - HL; m < D; ++m) z[k][m] = 0.0f;   // not read: the reverse pass completes these after the loop
         }
         g[k] = R.coef[k] * fast_exp2(-maha);
         S = (k == 0) ? g[k] : S + g[k];
