@@ -979,16 +979,24 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     // per-slot learning rate (0 = not trained) and l1 regulariser constant stay in registers;
     // the parameter and its Adam slots live in LDS between iterations.
     // fixed-range fake quant of the slot (pis; everything in mode 2): nudged range + step; qt[s] = index of the slot's
-    // mode-3 tensor (0 A_diagonal, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e; -1 none), qk[s] = its kernel
-    float lr[T::SPL], reg[T::SPL], qlo[T::SPL], qhi[T::SPL], qsc[T::SPL], qiv[T::SPL];
-    int qt[T::SPL], qk[T::SPL];
+    // mode-3 tensor (0 A_diagonal, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e; -1 none)
+    // meta[s] = tensor | kernel << 4 of the slot (-1: not a parameter).  The per-slot range arrays exist in the QUANT
+    // instantiations only: kept live across the loop they cost the other kernels ~20 VGPRs (the SSIM kernel lost a
+    // wave per SIMD over them); quantize_pis alone needs just the uniform constants of the pis range.
+    constexpr int QS = QUANT ? T::SPL : 1;
+    float lr[T::SPL], reg[T::SPL], qlo[QS], qhi[QS], qsc[QS], qiv[QS];
+    int meta[T::SPL], qt[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        qlo[s] = -__builtin_huge_valf(); qhi[s] = __builtin_huge_valf();
+        qsc[s] = qiv[s] = 0.0f;
+        qt[s] = -1;
+    }
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
         const int j = sub + s * G;
         lr[s] = reg[s] = 0.0f;
-        qlo[s] = -__builtin_huge_valf(); qhi[s] = __builtin_huge_valf();
-        qsc[s] = qiv[s] = 0.0f;
-        qt[s] = -1; qk[s] = 0;
+        meta[s] = -1;
         if (j < Lt::NPAR) {
             int tensor, kern; long off;
             decode_slot<D, C, K>(j, b, tensor, off, kern);
@@ -1007,12 +1015,16 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             reg[s] = (tensor == 0) ? a.reg_pi : ((tensor == 2) ? (a.kc.radial ? a.reg_u * (float)D : a.reg_u) : 0.0f);
             // fixed-range fake quant of this variable: the gradient passes inside the nudged range only
             const int qg = (tensor == 0) ? 3 : ((tensor == 1) ? 1 : ((tensor == 4) ? 4 : ((tensor == 5) ? 2 : 0)));
-            if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) {
-                qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; qsc[s] = a.kc.q_scale[qg]; qiv[s] = a.kc.q_inv[qg];
+            meta[s] = tensor | (kern << 4);
+            if constexpr (QUANT) {
+                if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) {
+                    qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; qsc[s] = a.kc.q_scale[qg]; qiv[s] = a.kc.q_inv[qg];
+                }
+                if (a.kc.qmode == 3 && tensor != 0 && !(tensor == 1 && !a.kc.q_musx))
+                    qt[s] = (tensor == 2) ? 0 : ((tensor == 3) ? 1 : ((tensor == 1) ? 2 : ((tensor == 5) ? 3 : 4)));
+            } else {
+                (void)qg;
             }
-            qk[s] = kern;
-            if (QUANT && a.kc.qmode == 3 && tensor != 0 && !(tensor == 1 && !a.kc.q_musx))
-                qt[s] = (tensor == 2) ? 0 : ((tensor == 3) ? 1 : ((tensor == 1) ? 2 : ((tensor == 5) ? 3 : 4)));
         } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
             const int k = j - Lt::S_CNT;
             s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
@@ -1046,7 +1058,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 for (int s = 0; s < T::SPL; ++s) {
                     const int j = sub + s * G;
                     if (j < Lt::NPAR && qt[s] >= 0) {
-                        const bool keep = fq_val(s_par[qk[s] * Lt::PK + Lt::O_PI], rp) > 0.0f;      // pis_mask = qpis > 0
+                        const bool keep = fq_val(s_par[(meta[s] >> 4) * Lt::PK + Lt::O_PI], rp) > 0.0f;      // pis_mask = qpis > 0
                         const float x = s_par[j];
 #pragma unroll
                         for (int t = 0; t < 5; ++t) {
@@ -1078,15 +1090,16 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 #pragma unroll
             for (int s = 0; s < T::SPL; ++s) {
                 const int j = sub + s * G;
-                if (j < Lt::NPAR && qsc[s] != 0.0f) {
+                if (meta[s] >= 0 && (meta[s] & 15) == 0) {          // a pis slot (this branch runs with kc.qpis only)
                     const float x = s_par[j];
-                    const float cl = fminf(fmaxf(x, qlo[s]), qhi[s]);
-                    s_par[Lt::LP_QPI + qk[s]] = floorf((cl - qlo[s]) * qiv[s] + 0.5f) * qsc[s] + qlo[s];
+                    const float cl = fminf(fmaxf(x, a.kc.q_nmin[3]), a.kc.q_nmax[3]);
+                    s_par[Lt::LP_QPI + (meta[s] >> 4)] = floorf((cl - a.kc.q_nmin[3]) * a.kc.q_inv[3] + 0.5f) * a.kc.q_scale[3] + a.kc.q_nmin[3];
                 }
             }
             wave_lds_sync();
             return;
         }
+        if constexpr (QUANT) {
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = sub + s * G;
@@ -1097,7 +1110,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     const float cl = fminf(fmaxf(x, qlo[s]), qhi[s]);
                     q = floorf((cl - qlo[s]) * qiv[s] + 0.5f) * qsc[s] + qlo[s];
                 }
-                if constexpr (QUANT) {
+                {
                     if (qt[s] >= 0) {
                         const float* o = s_rng + qt[s] * 8;
                         FqRange r;
@@ -1111,6 +1124,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             } else if (j == Lt::S_LOSS) {
                 s_q[Lt::LP_FROZEN] = s_par[Lt::LP_FROZEN];
             }
+        }
         }
         wave_lds_sync();
     };
@@ -1244,7 +1258,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                         const float* o = s_rng + qt[s] * 8;
                         const float x = s_par[j], v = x - o[4];
                         const bool zero = o[5] != 0.0f;
-                        const bool keep = fq_val(s_par[qk[s] * Lt::PK + Lt::O_PI], rp) > 0.0f;
+                        const bool keep = fq_val(s_par[(meta[s] >> 4) * Lt::PK + Lt::O_PI], rp) > 0.0f;
                         bel[s] = !zero && (v < o[0]);
                         abv[s] = !zero && (v > o[1]);
                         tlo[s] = keep && (x == o[6]);
@@ -1282,7 +1296,12 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             const float mv = s_mv[2 * jc];
             const float vv = s_mv[2 * jc + 1];
             float gsum = gq[s];
-            gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;     // fixed-range fake quant: straight-through inside
+            // fixed-range fake quant: straight-through inside the nudged range only
+            if constexpr (QUANT) {
+                gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;
+            } else {
+                if (patch_pis && meta[s] >= 0 && (meta[s] & 15) == 0) gsum = (pv >= kc.q_nmin[3] && pv <= kc.q_nmax[3]) ? gsum : 0.0f;
+            }
             if (clip > 0.0f) gsum = fminf(fmaxf(gsum, -clip), clip);
             const float alpha = lr[s] * bias;
             const float m2 = mv + (gsum - mv) * (1.0f - beta1);
