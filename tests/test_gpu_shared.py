@@ -437,3 +437,43 @@ def test_shared_radial_steering(ic):
     dg = np.diagonal(dp["A_diagonal"].cpu().numpy(), axis1=-2, axis2=-1)
     assert np.all(dg[:, 0] == dg[:, 1]) and np.abs(dg[:, 0] - a0).max() > 0.5
     eng.close()
+
+
+def test_gradient_buffer_goes_through_an_rccl_all_reduce():
+    """Multi-GPU shared mode: the accumulated fp64 gradient buffer (library memory wrapped as a torch tensor) is what
+    torch.distributed all-reduces between smoe_shared_accumulate and smoe_shared_apply.  One rank is all this box has:
+    the collective must accept the tensor and leave a one-rank sum unchanged, and the step after it must equal the
+    step without it."""
+    import socket
+    import torch.distributed as dist
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False)
+    eng = _engine(shape, bshape, C, K, False)
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    dp1, dp2 = _dev(p), _dev(p)
+    l1, l2 = eng.new_lists(), eng.new_lists()
+    s1, s2 = eng.new_adam_state(dp1), eng.new_adam_state(dp2)
+    eng.accumulate(T, dp1, l1)
+    eng.apply(dp1, s1)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        eng.accumulate(T, dp2, l2)
+        buf = eng.grad_buffer()
+        before = buf.clone()
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        assert buf.dtype == torch.float64 and torch.equal(buf, before) and float(before.abs().max()) > 0
+        eng.apply(dp2, s2)
+        torch.cuda.synchronize()
+        for k in dp1:
+            assert torch.equal(dp1[k], dp2[k]), k
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    eng.close()
