@@ -20,7 +20,7 @@ namespace {
 
 constexpr int SH_THREADS = 256;
 constexpr int SH_KC = 64;                 // kernels staged per LDS chunk
-constexpr float SQ = 0.84932180028801904272f;       // sqrt(0.5*log2(e)), see smoe_kernels.hip
+constexpr float SQ = 0.84932180028801904272f;       // sqrt(0.5*log2(e)), see smoe_block.cuh
 constexpr float INV_SQ = 1.17740022503374817543f;
 
 constexpr int tri(int l, int m) { return l * (l + 1) / 2 + m; }
