@@ -221,6 +221,11 @@ typedef struct smoe_shared_context* smoe_shared_handle;
 
 int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg);
 int smoe_shared_destroy(smoe_shared_handle h);
+/* Per-pixel loss weights of the whole image (the graph's loss_weights placeholder fed from Smoe.loss_mask,
+ * smoe.py:550,932,1674-1677): caller-owned device array [num_batches][Nb] in batch order, indexed with the GLOBAL
+ * batch index by every later forward / accumulate / fit call; it must stay alive until cleared with NULL or the
+ * handle is destroyed.  Ignored with ssim_opt, as in the reference. */
+int smoe_shared_set_loss_weights(smoe_shared_handle h, const float* loss_w);
 int smoe_shared_num_batches(smoe_shared_handle h);
 int smoe_shared_list_words(smoe_shared_handle h);
 

@@ -728,13 +728,14 @@ def _bcast(p, NB):
     return {k: np.broadcast_to(v, (NB,) + v.shape[1:]) for k, v in p.items()}
 
 
-def shared_pass(p, target, coords, lists, cfg: OracleConfig, dtype=np.float32, want_grads=False, halo_coords=None):
+def shared_pass(p, target, coords, lists, cfg: OracleConfig, dtype=np.float32, want_grads=False, halo_coords=None,
+                loss_w=None):
     """One run_batched pass (smoe.py:1606-1793) in shared-kernel mode.  p: leading axis 1;
     target (NB,Nb,C); coords (NB,Nb,d); lists (NB,K) bool.  Returns the per-batch forward dict plus
     ``loss_val``/``mse_val`` (pixel-weighted means, smoe.py:1758-1759), ``lists_new`` (1763-1766)
     and, with want_grads, ``grads`` = SUM over batches of the per-batch gradients (smoe.py:1150)."""
     NB = target.shape[0]
-    f = forward(_bcast(p, NB), target, coords, lists, cfg, None, dtype, want_grads=want_grads)
+    f = forward(_bcast(p, NB), target, coords, lists, cfg, loss_w, dtype, want_grads=want_grads)      # loss_w: (NB,Nb) or None
     f["loss_val"] = float(np.mean(f["loss"]))                       # equal-size batches
     f["mse_val"] = float(np.mean(f["mse_op"]))
     f["lists_new"] = f["active_new"]
@@ -771,7 +772,7 @@ def shared_readmit(p, lists, coords, cfg: OracleConfig, dtype=np.float32):   # c
 
 
 def shared_fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int = 100, ukl_iter=None,
-               dtype=np.float32, halo_coords=None):
+               dtype=np.float32, halo_coords=None, loss_w=None):
     """Smoe.train in shared-kernel mode (smoe.py:1485-1603): iteration-0 eval pass, per iteration a
     train pass (prune lists) + one Adam step on the accumulated gradients, readmission every
     ukl_iter, eval + best snapshot every val_iter."""
@@ -783,20 +784,20 @@ def shared_fit(p, target, coords, cfg: OracleConfig, n_iters: int, val_iter: int
     p = {k: v.astype(T) for k, v in p.items()}
     state = new_adam_state(p)
     lists = np.ones((NB, K), dtype=bool)                              # smoe.py:315
-    f0 = shared_pass(p, target, coords, lists, cfg, T, halo_coords=halo_coords)
+    f0 = shared_pass(p, target, coords, lists, cfg, T, halo_coords=halo_coords, loss_w=loss_w)
     lists = f0["lists_new"]
     hist = {"iter": [0], "loss": [f0["loss_val"]], "mse": [f0["mse_val"]]}
     best, best_loss = {k: v.copy() for k, v in p.items()}, f0["loss_val"]
     train_losses = []
     for i in range(1, n_iters + 1):
-        f = shared_pass(p, target, coords, lists, cfg, T, want_grads=True, halo_coords=halo_coords)
+        f = shared_pass(p, target, coords, lists, cfg, T, want_grads=True, halo_coords=halo_coords, loss_w=loss_w)
         lists = f["lists_new"]
         p = adam_step(p, f["grads"], state, cfg, T)
         train_losses.append(f["loss_val"])
         if i % ukl_iter == 0:
             lists = shared_readmit(p, lists, coords if halo_coords is None else halo_coords, cfg, T)
         if i % val_iter == 0:
-            fv = shared_pass(p, target, coords, lists, cfg, T, halo_coords=halo_coords)
+            fv = shared_pass(p, target, coords, lists, cfg, T, halo_coords=halo_coords, loss_w=loss_w)
             lists = fv["lists_new"]
             if fv["loss_val"] < best_loss:
                 best_loss, best = fv["loss_val"], {k: v.copy() for k, v in p.items()}

@@ -464,6 +464,7 @@ struct smoe_shared_context {
     float* d_probes;      // [NB][D][3]
     double* d_racc;       // [K*PK + K]
     float* d_ssim_T;      // ssim_opt: banded tap tables of the batch shape
+    const float* loss_w;  // caller-owned [NB][Nb] loss weights (smoe_shared_set_loss_weights) or null
     smoe::KernelConsts kc;
 };
 
@@ -479,6 +480,7 @@ void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
         a.image_shape[l] = (l < c.dim) ? c.image_shape[l] : 1;
     }
     a.overlap = c.overlap;
+    a.loss_w = h->loss_w;
     a.ssim = c.ssim_opt ? 1 : 0;
     a.ssim_T = h->d_ssim_T;
     a.ssim_off = (int)(smoe::shared_lds_bytes(c.dim, c.channels, c.kernels, h->KW) / sizeof(float));
@@ -583,7 +585,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         }
     }
     const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
-    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr;
+    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->loss_w = nullptr;
     if (cfg->ssim_opt) {
         const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
                             smoe::shared_ssim_lds_bytes(cfg->channels, (int)Nb, cfg->batch_shape[0], cfg->batch_shape[1]);
@@ -655,6 +657,12 @@ int smoe_shared_destroy(smoe_shared_handle h) {
     if (h->d_racc) (void)hipFree(h->d_racc);
     if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
     delete h;
+    return SMOE_OK;
+}
+
+int smoe_shared_set_loss_weights(smoe_shared_handle h, const float* loss_w) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_set_loss_weights: null handle");
+    h->loss_w = loss_w;
     return SMOE_OK;
 }
 

@@ -139,6 +139,7 @@ struct SharedArgs {
     int update_lists;
     KernelConsts kc;
     float reg_pi, reg_u;
+    const float* loss_w;      // [num_batches][Nb] per-pixel loss weights of the WHOLE image (global batch index) or null
     const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
     int ssim;                 // 1: loss_pixel = 1 - SSIM of the batch
     int ssim_off;             // float offset of the SSIM planes inside the workgroup's LDS

@@ -383,19 +383,22 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
 #pragma unroll
     for (int p = 0; p < PXL; ++p) {
         dot[p] = 0.0f;
+        // per-pixel loss weight (the graph's loss_weights placeholder, smoe.py:550,932,1674-1677); global batch index
+        const float lw = (a.loss_w != nullptr && pv[p]) ? a.loss_w[(size_t)(a.b0 + b) * Nb + p * SH_THREADS + tid] : 1.0f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float yc = __builtin_amdgcn_fmed3f(y[p][c], 0.0f, a.kc.nudged_max);
             const float q = floorf(fmaf(yc, a.kc.inv_scale, 0.5f)) * a.kc.scale;
             const float diff = q - t[p][c];
             const float ad = fabsf(diff) - a.kc.epsm;
+            const float cwl = a.kc.cw[c] * lw;
             if (pv[p]) {
                 sse_part = fmaf(diff, diff, sse_part);
-                loss_part = fmaf(a.kc.cw[c], ad * ad, loss_part);
+                loss_part = fmaf(cwl, ad * ad, loss_part);
                 if (a.recon != nullptr) a.recon[((size_t)b * C + c) * Nb + p * SH_THREADS + tid] = q;
             }
             const float sg = __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -1.0f, 1.0f);
-            const float gm = (a.kc.cw[c] + a.kc.cw[c]) * (ad * sg);
+            const float gm = (cwl + cwl) * (ad * sg);
             Gc[p][c] = (pv[p] && yc == y[p][c]) ? gm : 0.0f;
             dot[p] = fmaf(Gc[p][c], y[p][c], dot[p]);
         }

@@ -411,6 +411,15 @@ class SharedEngine:
         _lib.check(self.lib.smoe_shared_update_kernel_list(self._h, first_batch, lists.shape[0], C.byref(cp), _ptr(lists),
                                                            self._stream()))
 
+    def set_loss_weights(self, loss_w: Optional[torch.Tensor]):
+        """[num_batches, Nb] float32 device tensor of per-pixel loss weights for the WHOLE image (or None to clear);
+        the engine keeps a reference so the memory stays alive."""
+        if loss_w is not None:
+            assert loss_w.dtype == torch.float32 and loss_w.is_contiguous() and loss_w.device == self.device
+            assert tuple(loss_w.shape) == (self.num_batches, self.batch_pixels)
+        self._loss_w = loss_w
+        _lib.check(self.lib.smoe_shared_set_loss_weights(self._h, _ptr(loss_w)))
+
     def grad_buffer(self) -> torch.Tensor:
         """The gradient accumulation buffer as a float64 device tensor view (for the all-reduce
         between accumulate() and apply() when batches are sharded over ranks)."""

@@ -611,7 +611,7 @@ class SharedSmoe:
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
                  engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
                  upper_bounds=None, only_y_gamma=False, use_diff_center=False, ssim_opt=False, train_inverse_cov=True,
-                 radial_as=False, **unsupported):
+                 radial_as=False, loss_mask=None, **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
@@ -691,6 +691,15 @@ class SharedSmoe:
         self._best = {k: v.clone() for k, v in self._params.items()}
         self._state = self._engine.new_adam_state(self._params)
         self._lists = self._engine.new_lists(self.hi - self.lo)           # smoe.py:315
+        # loss_mask (smoe.py:1674-1677): per-pixel loss weights, cut into the batches like the image
+        self.loss_mask = loss_mask
+        self._loss_w = None
+        if loss_mask is not None:
+            if self.ssim_opt:
+                raise NotImplementedError("ssim_opt ignores loss weights (as the reference does)")
+            lm, _ = blk.image_to_blocks(np.asarray(loss_mask, dtype=np.float32)[..., None], bs)
+            self._loss_w = torch.from_numpy(np.ascontiguousarray(lm.reshape(self.num_batches, -1))).to(dev)
+            self._engine.set_loss_weights(self._loss_w)
         self.losses, self.mses, self.num_pis, self.num_svs = [], [], [], []
         self.losses_history, self.mses_history = [], []
         self.best_loss, self.best_mse = None, []
@@ -724,6 +733,8 @@ class SharedSmoe:
                 self._engine.close()
             self._engine = self._factory(cfg, self._device)
             self._engine_key = key
+            if getattr(self, "_loss_w", None) is not None:                # a re-created engine needs the weights again
+                self._engine.set_loss_weights(self._loss_w)
 
     @property
     def kernel_list_per_batch(self):

@@ -218,6 +218,13 @@ class OracleSharedEngine:
     def _p(self, params):
         return {k: params[k].numpy()[None] for k in NAMES}
 
+    def set_loss_weights(self, loss_w):
+        self._loss_w = None if loss_w is None else loss_w.numpy()
+
+    def _lw(self, first_batch, nb):
+        lw = getattr(self, "_loss_w", None)
+        return None if lw is None else lw[first_batch:first_batch + nb]
+
     def _halo(self, first_batch, nb):
         return None if self.halo is None else self.halo[first_batch:first_batch + nb]
 
@@ -225,7 +232,7 @@ class OracleSharedEngine:
         nb = lists.shape[0]
         tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
         f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg,
-                          halo_coords=self._halo(first_batch, nb))
+                          halo_coords=self._halo(first_batch, nb), loss_w=self._lw(first_batch, nb))
         if update_lists:
             self._setbits(lists, f["lists_new"])
         return {"loss": torch.from_numpy(f["loss"].astype(np.float32)), "sse": torch.from_numpy(f["sse"].astype(np.float32)),
@@ -246,7 +253,7 @@ class OracleSharedEngine:
         nb = lists.shape[0]
         tgt = np.ascontiguousarray(target.numpy().transpose(0, 2, 1))
         f = o.shared_pass(self._p(params), tgt, self.coords[first_batch:first_batch + nb], self._mask(lists), self.ocfg,
-                          np.float32, want_grads=True, halo_coords=self._halo(first_batch, nb))
+                          np.float32, want_grads=True, halo_coords=self._halo(first_batch, nb), loss_w=self._lw(first_batch, nb))
         self._setbits(lists, f["lists_new"])
         buf = self.grad_buffer()
         flat = np.concatenate([f["grads"][k][0].astype(np.float64).ravel() for k in NAMES])

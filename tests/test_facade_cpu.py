@@ -522,3 +522,28 @@ def test_shared_facade_quantises_at_validation_points():
     q, r = s.get_qreconstruction(), s.get_reconstruction()
     assert q.shape == r.shape and 0 < np.abs(q - r).mean() < 0.05
     assert s.get_qmses()[-1][1] >= s.get_mses()[-1][1] * 0.9          # quantised parameters reconstruct slightly worse
+
+
+def test_shared_facade_with_a_loss_mask():
+    """loss_mask in the shared mode (smoe.py:550,932,1674-1677): per-pixel weights on the margin loss."""
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(32, 48, seed=16)
+    mask = np.random.default_rng(1).uniform(0, 1, size=(32, 48)).astype(np.float32)
+    mask[:8] = 0.0
+    s = SharedSmoe(img, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True, train_inverse_cov=False,
+                   loss_mask=mask, engine_factory=OracleSharedEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(4, val_iter=2)
+    p0 = o.shared_init_params(img, [3, 4])
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    mb, _ = blk.image_to_blocks(mask[..., None], (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=12, lr_steer=0.01)
+    pn, _, info = o.shared_fit(p0, tb.reshape(6, -1, 1), o.global_batch_coords((32, 48), (16, 16)), cfg, 4, val_iter=2,
+                               loss_w=mb.reshape(6, -1))
+    plain = o.shared_fit(p0, tb.reshape(6, -1, 1), o.global_batch_coords((32, 48), (16, 16)), cfg, 4, val_iter=2)[2]
+    got = s.get_params()
+    for k in got:
+        assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
+    assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
+    assert info["hist"]["loss"][0] < 0.8 * plain["hist"]["loss"][0]            # the mask really weighs the loss

@@ -477,3 +477,39 @@ def test_gradient_buffer_goes_through_an_rccl_all_reduce():
         if own_group:
             dist.destroy_process_group()
     eng.close()
+
+
+def test_shared_loss_weights():
+    """smoe_shared_set_loss_weights: per-pixel weights on the margin loss and its gradients, indexed by the global
+    batch id (so that a range of batches -- a rank's shard -- sees its own weights)."""
+    shape, bshape, C, kpd = (64, 96), (32, 32), 3, [3, 5]
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, True, pis_l1=0.05, u_l1=0.001)
+    lw = np.random.default_rng(3).uniform(0, 1, size=(NB, tgt.shape[1])).astype(np.float32)
+    lw[1] = 0.0
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, True, pis_l1=0.05, u_l1=0.001)
+    LW = torch.from_numpy(lw).cuda()
+    eng.set_loss_weights(LW)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True, update_lists=False)
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    f64 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, lw, np.float64, want_grads=True, q_override=recon)
+    assert np.allclose(fw["loss"].cpu().numpy(), f64["loss"], rtol=3e-5, atol=1e-9)
+    g64 = {k: v.sum(axis=0) for k, v in f64["grads"].items()}
+    st = eng.new_adam_state(dp)
+    h = NB // 2
+    eng.accumulate(T[:h].contiguous(), dp, dl[:h], first_batch=0)             # two ranges: the weights follow the batch id
+    eng.accumulate(T[h:].contiguous(), dp, dl[h:], first_batch=h)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    bad = (np.abs(f64["w"] - 0.5 / 256) < 1e-6).any() or ((np.abs(f64["y"]) < 1e-6) | (np.abs(f64["y"] - 1) < 1e-6)).any()
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g64[name]).max() + 1e-30
+        err = np.abs(st.m[name].cpu().numpy() / 0.1 - g64[name]).max() / scale
+        assert err < (2e-3 if bad else 5e-5), (name, err)
+    eng.set_loss_weights(None)
+    f1 = eng.forward(T, _dev(p), dl, want_recon=False, update_lists=False)     # same parameters as fw, weights cleared
+    assert float(f1["loss"][1]) > float(fw["loss"][1])                         # batch 1 had weight 0: regularisers only
+    eng.close()
