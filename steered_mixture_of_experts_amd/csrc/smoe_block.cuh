@@ -834,7 +834,7 @@ __device__ __forceinline__ float ssim_block16(float* __restrict__ X, const float
             const float N0 = num0 + SSIM_C1, D0 = den0 + SSIM_C1;
             const float N1 = (pxy * 2.0f - num0) + SSIM_C2;
             const float D1 = ((sx + sy) - den0) + SSIM_C2;
-            const float r0 = 1.0f / D0, r1 = 1.0f / D1;
+            const float r0 = fast_rcp(D0), r1 = fast_rcp(D1);      // 1 ulp: far inside the 2e-5 loss tolerance
             const float lum = N0 * r0, cs = N1 * r1;
             acc = fmaf(lum, cs, acc);
             if (GRAD) {
@@ -1218,7 +1218,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
 
         // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
-        const float bias = sqrtf(1.0f - b2p) / (1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
+        const float bias = __builtin_amdgcn_sqrtf(1.0f - b2p) * fast_rcp(1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
         // gradients w.r.t. the (quantised) graph variables incl. the l1 terms
         float gq[T::SPL];
 #pragma unroll
@@ -1306,7 +1306,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             const float alpha = lr[s] * bias;
             const float m2 = mv + (gsum - mv) * (1.0f - beta1);
             const float v2 = vv + (gsum * gsum - vv) * (1.0f - beta2);
-            const float p2 = pv - (m2 * alpha) / (sqrtf(v2) + adam_eps);
+            // hardware sqrt / rcp (1 ulp each): the step changes by ~2e-7 relative, an IEEE sqrt + division per slot cost ~14 VALU
+            const float p2 = pv - (m2 * alpha) * fast_rcp(__builtin_amdgcn_sqrtf(v2) + adam_eps);
             const bool upd = (j < Lt::NPAR) && (lr[s] != 0.0f) && !frozen;
             newp[s] = upd ? p2 : pv;
             if (upd) { s_mv[2 * jc] = m2; s_mv[2 * jc + 1] = v2; }
