@@ -207,7 +207,7 @@ typedef struct smoe_shared_config {
     int32_t start_pis;
     int32_t only_y_gamma;
     int32_t overlap;                    /* overlap_of_batches (smoe.py:244), pixels per side */
-    int32_t quantization_mode;          /* as smoe_config; 0/1/2 (mode 3 is not built for this mode)  smoe.py:474-496 */
+    int32_t quantization_mode;          /* as smoe_config; mode 3 ranges are IMAGE-wide min / max  smoe.py:474-530 */
     int32_t quantize_pis;
     int32_t bit_depths[5];
     float   lower_bounds[5];
@@ -215,6 +215,7 @@ typedef struct smoe_shared_config {
     int32_t ssim_opt;                   /* loss_pixel = 1 - SSIM of every batch (2-d, >= 5 pixels per axis)  smoe.py:980-1011 */
     int32_t train_inverse_cov;          /* as smoe_config                                       smoe.py:734-735,791-793 */
     int32_t radial_as;                  /* as smoe_config: A_diagonal [K,d,d] with equal diagonals        smoe.py:714-719 */
+    int32_t kernel_count_as_norm_l1;    /* pis_l1 / count(qpis > 0) over the image instead of / start_pis  smoe.py:1022-1027 */
 } smoe_shared_config;
 
 typedef struct smoe_shared_context* smoe_shared_handle;

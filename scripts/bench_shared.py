@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--quantization-mode", type=int, default=0, help="0, 2 or 3 (fake-quantised graph)")
     args = ap.parse_args()
     shape, bs, C = tuple(args.image), tuple(args.batch), args.channels
     d = len(shape)
@@ -34,7 +35,8 @@ def main():
     kpd = list(args.kernels_per_dim)
     p0 = {k: v[0] for k, v in blk.init_block_params(img[None], kpd).items()}
     K = p0["pis"].shape[0]
-    eng = SharedEngine(SharedConfig(image_shape=shape, batch_shape=bs, channels=C, kernels=K, use_yuv=(C == 3)))
+    eng = SharedEngine(SharedConfig(image_shape=shape, batch_shape=bs, channels=C, kernels=K, use_yuv=(C == 3),
+                                    quantization_mode=args.quantization_mode, quantize_pis=args.quantization_mode >= 2))
     tb, _ = blk.image_to_blocks(img, bs)
     T = torch.from_numpy(blk.to_planar(tb)).cuda()
     dp = {k: torch.from_numpy(v).cuda() for k, v in p0.items()}
@@ -61,7 +63,7 @@ def main():
     psnr1 = -10 * np.log10(float(f1["sse"].sum()) / (npx * C))
     bits = lists.cpu().numpy().view(np.uint32)
     kact = float(np.mean([bin(int(x)).count("1") for row in bits for x in row]) * bits.shape[1])
-    out = {"mode": "shared-kernel image fit (SURVEY 8(f-1))", "image": list(shape), "batch": list(bs), "channels": C,
+    out = {"mode": "shared-kernel image fit (SURVEY 8(f-1))", "quantization_mode": args.quantization_mode, "image": list(shape), "batch": list(bs), "channels": C,
            "kernels": K, "steps": args.steps, "ms_per_step": round(ms / args.steps, 4),
            "value": round(npx * args.steps / (ms * 1e-3) / 1e6, 1), "unit": "Mpixel-iters/s",
            "mean_listed_kernels_per_batch_at_end": round(kact, 2),

@@ -57,7 +57,7 @@ class SmoeSharedConfig(C.Structure):
         ("only_y_gamma", C.c_int32), ("overlap", C.c_int32),
         ("quantization_mode", C.c_int32), ("quantize_pis", C.c_int32), ("bit_depths", C.c_int32 * 5),
         ("lower_bounds", C.c_float * 5), ("upper_bounds", C.c_float * 5), ("ssim_opt", C.c_int32),
-        ("train_inverse_cov", C.c_int32), ("radial_as", C.c_int32),
+        ("train_inverse_cov", C.c_int32), ("radial_as", C.c_int32), ("kernel_count_as_norm_l1", C.c_int32),
     ]
 
 

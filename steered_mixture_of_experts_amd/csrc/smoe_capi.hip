@@ -464,6 +464,8 @@ struct smoe_shared_context {
     float* d_probes;      // [NB][D][3]
     double* d_racc;       // [K*PK + K]
     float* d_ssim_T;      // ssim_opt: banded tap tables of the batch shape
+    float* d_qrng;        // SharedRangesArgs records (mode-3 ranges, count of qpis > 0)
+    bool need_ranges;     // quantization_mode 3 or kernel_count_as_norm_l1
     const float* loss_w;  // caller-owned [NB][Nb] loss weights (smoe_shared_set_loss_weights) or null
     smoe::KernelConsts kc;
 };
@@ -490,6 +492,15 @@ void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
     a.reg_u = c.u_l1;
     a.racc = h->d_racc;
     a.nact = h->d_racc + (size_t)c.kernels * h->PK;
+    a.qrng = h->d_qrng;
+}
+
+// the image-wide records follow the parameters of THIS call (the C ABI is stateless in the parameters)
+hipError_t refresh_ranges(const smoe_shared_context* h, const smoe_params* p, hipStream_t st) {
+    if (!h->need_ranges) return hipSuccess;
+    smoe::SharedRangesArgs r;
+    r.p = *p; r.qrng = h->d_qrng; r.K = h->cfg.kernels; r.kc = h->kc;
+    return smoe::launch_shared_ranges(r, h->cfg.dim, h->cfg.channels, st);
 }
 
 int check_range(const smoe_shared_context* h, int first, int count, const char* who) {
@@ -522,8 +533,6 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         const int qrc = check_quant_config(cfg->quantization_mode, cfg->quantize_pis, cfg->bit_depths, cfg->lower_bounds,
                                            cfg->upper_bounds, &qmsg);
         if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_shared_create: ") + qmsg);
-        if (cfg->quantization_mode == 3)
-            return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: quantization_mode 3 (image-wide min/max ranges) is not built for the shared-kernel mode");
     }
     if (cfg->radial_as && cfg->quantization_mode >= 2)
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: radial_as with quantization_mode 2/3 is not built");
@@ -585,7 +594,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         }
     }
     const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
-    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->loss_w = nullptr;
+    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->d_qrng = nullptr; h->loss_w = nullptr;
+    h->need_ranges = cfg->quantization_mode == 3 || cfg->kernel_count_as_norm_l1 != 0;
     if (cfg->ssim_opt) {
         const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
                             smoe::shared_ssim_lds_bytes(cfg->channels, (int)Nb, cfg->batch_shape[0], cfg->batch_shape[1]);
@@ -600,6 +610,8 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     if (e == hipSuccess) e = hipMemcpy(h->d_axes, axes.data(), sizeof(float) * axes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * probes.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(h->d_racc, 0, sizeof(double) * nacc);
+    if (e == hipSuccess) e = hipMalloc(&h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
+    if (e == hipSuccess) e = hipMemset(h->d_qrng, 0, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess && cfg->ssim_opt) {
         const int bh = cfg->batch_shape[0], bw = cfg->batch_shape[1];
         std::vector<float> tabs((size_t)11 * (bh + bw));
@@ -613,6 +625,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         if (h->d_probes) (void)hipFree(h->d_probes);
         if (h->d_racc) (void)hipFree(h->d_racc);
         if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
+        if (h->d_qrng) (void)hipFree(h->d_qrng);
         delete h;
         return fail_hip(e, "smoe_shared_create: workspace");
     }
@@ -643,7 +656,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     }
     kc.inverse_cov = cfg->train_inverse_cov ? 1 : 0;
     kc.radial = cfg->radial_as ? 1 : 0;
-    kc.kcount_norm = 0;
+    kc.kcount_norm = cfg->kernel_count_as_norm_l1 ? 1 : 0;
     kc.pis_l1_raw = cfg->pis_l1;
     *out = h;
     return SMOE_OK;
@@ -656,6 +669,7 @@ int smoe_shared_destroy(smoe_shared_handle h) {
     if (h->d_probes) (void)hipFree(h->d_probes);
     if (h->d_racc) (void)hipFree(h->d_racc);
     if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
+    if (h->d_qrng) (void)hipFree(h->d_qrng);
     delete h;
     return SMOE_OK;
 }
@@ -689,6 +703,7 @@ int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_b
     fill_shared_args(h, a);
     a.target = target; a.p = *p; a.lists = lists; a.b0 = first_batch; a.NB = num_batches;
     a.loss = loss; a.sse = sse; a.recon = recon; a.argmax = argmax; a.update_lists = update_lists;
+    HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_forward ranges");
     HIP_TRY(smoe::launch_shared_pass(a, h->cfg.dim, h->cfg.channels, false, (hipStream_t)stream), "smoe_shared_forward launch");
     return SMOE_OK;
 }
@@ -705,6 +720,7 @@ int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t nu
     fill_shared_args(h, a);
     a.target = target; a.p = *p; a.lists = lists; a.b0 = first_batch; a.NB = num_batches;
     a.loss = loss; a.sse = sse; a.recon = nullptr; a.argmax = nullptr; a.update_lists = 1;
+    HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_accumulate ranges");
     HIP_TRY(smoe::launch_shared_pass(a, h->cfg.dim, h->cfg.channels, true, (hipStream_t)stream), "smoe_shared_accumulate launch");
     return SMOE_OK;
 }
@@ -724,6 +740,8 @@ int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, 
     a.kc = h->kc;
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
     a.reg_u = c.u_l1;
+    a.qrng = h->d_qrng;
+    HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_apply ranges");
     HIP_TRY(smoe::launch_shared_adam(a, c.dim, c.channels, (hipStream_t)stream), "smoe_shared_apply launch");
     s->beta1_power *= c.beta1;
     s->beta2_power *= c.beta2;
@@ -754,7 +772,8 @@ int smoe_shared_update_kernel_list(smoe_shared_handle h, int32_t first_batch, in
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::SharedReadmitArgs a;
     a.p = *p; a.lists = lists; a.probes = h->d_probes + (size_t)first_batch * h->cfg.dim * 3;
-    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW; a.kc = h->kc;
+    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW; a.kc = h->kc; a.qrng = h->d_qrng;
+    HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_update_kernel_list ranges");
     HIP_TRY(smoe::launch_shared_readmit(a, h->cfg.dim, (hipStream_t)stream), "smoe_shared_update_kernel_list launch");
     return SMOE_OK;
 }

@@ -143,6 +143,7 @@ struct SharedArgs {
     const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
     int ssim;                 // 1: loss_pixel = 1 - SSIM of the batch
     int ssim_off;             // float offset of the SSIM planes inside the workgroup's LDS
+    const float* qrng;        // image-wide records of shared_ranges_kernel (mode 3 ranges, count of qpis > 0); see SharedRangesArgs
 };
 
 struct SharedAdamArgs {
@@ -154,7 +155,8 @@ struct SharedAdamArgs {
     float lr_expert, lr_pis, lr_steer;
     int train_pis, train_musx, train_gammas, use_det, only_y_gamma;
     float reg_pi, reg_u;
-    KernelConsts kc;          // fixed-range fake quant of the variables (quantize_pis, quantization_mode 2)
+    KernelConsts kc;          // fake quant of the variables (quantize_pis, quantization_mode 2 / 3)
+    float* qrng;              // records of shared_ranges_kernel for the CURRENT parameters (mode 3, kernel_count_as_norm_l1)
 };
 
 struct SharedReadmitArgs {
@@ -162,6 +164,19 @@ struct SharedReadmitArgs {
     uint32_t* lists;          // [nb][KW]
     const float* probes;      // [nb][D][3]
     int NB, K, KW;
+    KernelConsts kc;
+    const float* qrng;
+};
+
+// Image-wide quantities of the fake-quantised graph, recomputed from the parameters before every launch that reads them:
+// record t = 0..4 (A_diagonal, A_corr, musX, nu_e, gamma_e) = 8 floats {nudged min, nudged max, step, 1/step, offset
+// added back, zero-range flag, raw min, raw max} of quantization_mode 3 (min / max over the kernels with qpis > 0,
+// smoe.py:497-530); qrng[40] = count(qpis > 0) (kernel_count_as_norm_l1, smoe.py:1012,1022-1027).
+static constexpr int SHARED_QRNG_FLOATS = 48;
+struct SharedRangesArgs {
+    smoe_params p;
+    float* qrng;
+    int K;
     KernelConsts kc;
 };
 
@@ -171,6 +186,7 @@ bool shared_supported(int D, int C, int Nb);
 hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st);
 hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st);
 hipError_t launch_shared_readmit(const SharedReadmitArgs& a, int D, hipStream_t st);
+hipError_t launch_shared_ranges(const SharedRangesArgs& a, int D, int C, hipStream_t st);
 
 const Variant* variants(int* count);
 hipError_t launch_readmit(const ReadmitArgs& a, int D, hipStream_t st);

@@ -13,6 +13,7 @@
 
 #include "smoe_device.h"
 #include "smoe_ssim.cuh"
+#include "smoe_fq.cuh"
 
 namespace smoe {
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // Fixed-range fake quant of the variables inside the graph (quantize_pis; quantization_mode 2; smoe.py:474-496):
-// group g: 0 A, 1 musX, 2 nu_e, 3 pis, 4 gamma_e.  (Mode 3 needs image-wide ranges and is not built for this mode.)
+// group g: 0 A, 1 musX, 2 nu_e, 3 pis, 4 gamma_e.
 __device__ __forceinline__ bool fq_on(const KernelConsts& kc, int g) { return (g == 3) ? (kc.qpis != 0) : (kc.qmode == 2); }
 __device__ __forceinline__ float fqv(float x, const KernelConsts& kc, int g) {
     if (!fq_on(kc, g)) return x;
@@ -61,6 +62,22 @@ __device__ __forceinline__ float fqv(float x, const KernelConsts& kc, int g) {
 }
 __device__ __forceinline__ bool fq_pass(float x, const KernelConsts& kc, int g) {
     return !fq_on(kc, g) || (x >= kc.q_nmin[g] && x <= kc.q_nmax[g]);
+}
+// Variable of mode-3 tensor t (0 A_diagonal, 1 A_corr, 2 musX, 3 nu_e, 4 gamma_e) as the graph sees it: fixed ranges
+// (mode 2) by group, or the image-wide min / max range record of shared_ranges_kernel (mode 3, smoe.py:497-530)
+__device__ __forceinline__ float fqt(float x, const KernelConsts& kc, const float* rng, int t) {
+    if (kc.qmode == 3) {
+        if (t == 2 && !kc.q_musx) return x;                      // musX is quantised only when trained (smoe.py:506)
+        const float* o = rng + t * 8;
+        FqRange r;
+        r.nmin = o[0]; r.nmax = o[1]; r.scale = o[2]; r.inv = o[3]; r.back = o[4]; r.zero = o[5] != 0.0f;
+        return fq_val(x, r);
+    }
+    return fqv(x, kc, (t <= 1) ? 0 : ((t == 2) ? 1 : ((t == 3) ? 2 : 4)));
+}
+// pis_l1 normaliser (smoe.py:1022-1027): start_pis, or the image-wide count of kernels with qpis > 0
+__device__ __forceinline__ float reg_pi_of(float reg_pi, const KernelConsts& kc, const float* rng) {
+    return kc.kcount_norm ? kc.pis_l1_raw / fmaxf(rng[40], 1.0f) : reg_pi;
 }
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -158,7 +175,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int l = 0; l < D; ++l)
 #pragma unroll
                 for (int m = 0; m <= l; ++m) {
-                    A[l][m] = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
+                    A[l][m] = fqt((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, a.qrng, (l == m) ? 0 : 1);
                     if (l == m) det *= A[l][m];
                     // train_inverse_cov: the coefficients c_lm of r^T A' r over l >= m, A' = SQ^2 A (smoe.py:734-735,791-793)
                     r[L::O_AS + tri(l, m)] = ic ? ((l == m) ? SQ * SQ : 2.0f * SQ * SQ) * A[l][m] : SQ * A[l][m];
@@ -167,20 +184,20 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int m = 0; m < D; ++m) {
                 float cz = 0.0f;
                 if (ic) {
-                    cz = fqv(a.p.musX[(size_t)k * D + m], a.kc, 1);        // the centre itself: r = x - mu per pixel
+                    cz = fqt(a.p.musX[(size_t)k * D + m], a.kc, a.qrng, 2);   // the centre itself: r = x - mu per pixel
                 } else {
 #pragma unroll
-                    for (int l = m; l < D; ++l) cz = fmaf(fqv(a.p.musX[(size_t)k * D + l], a.kc, 1), SQ * A[l][m], cz);
+                    for (int l = m; l < D; ++l) cz = fmaf(fqt(a.p.musX[(size_t)k * D + l], a.kc, a.qrng, 2), SQ * A[l][m], cz);
                 }
                 r[L::O_CZ + m] = cz;
             }
             const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
             r[L::O_COEF] = nq * fqv(a.p.pis[k], a.kc, 3);
 #pragma unroll
-            for (int c = 0; c < C; ++c) r[L::O_NU + c] = fqv(a.p.nu_e[(size_t)k * C + c], a.kc, 2);
+            for (int c = 0; c < C; ++c) r[L::O_NU + c] = fqt(a.p.nu_e[(size_t)k * C + c], a.kc, a.qrng, 3);
 #pragma unroll
             for (int i = 0; i < D * C; ++i)
-                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? fqv(a.p.gamma_e[(size_t)k * D * C + i], a.kc, 4) : 0.0f;
+                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? fqt(a.p.gamma_e[(size_t)k * D * C + i], a.kc, a.qrng, 4) : 0.0f;
         }
         __syncthreads();
     };
@@ -274,10 +291,10 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         float Aq[D][D], rr[D];
 #pragma unroll
         for (int l = 0; l < D; ++l) {
-            rr[l] = xh[l] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1);
+            rr[l] = xh[l] - fqt(a.p.musX[(size_t)k * D + l], a.kc, a.qrng, 2);
 #pragma unroll
             for (int m = 0; m <= l; ++m) {
-                Aq[l][m] = fqv((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0);
+                Aq[l][m] = fqt((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, a.qrng, (l == m) ? 0 : 1);
                 if (l == m) det *= Aq[l][m];
             }
         }
@@ -485,10 +502,11 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         float lossv = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
         if (SSIM) lossv += 1.0f;                                      // smoe.py:1010: 1 - ssim
         if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {                    // smoe.py:1027,1044 over the batch's active kernels
+            const float rp = reg_pi_of(a.reg_pi, a.kc, a.qrng);
             for (int i = 0; i < Kact; ++i) {
                 const int k = s_list[i];
-                lossv += a.reg_pi * fqv(a.p.pis[k], a.kc, 3);
-                for (int l = 0; l < D; ++l) lossv += a.reg_u * fqv(a.p.A_diagonal[((size_t)k * D + l) * D + l], a.kc, 0);
+                lossv += rp * fqv(a.p.pis[k], a.kc, 3);
+                for (int l = 0; l < D; ++l) lossv += a.reg_u * fqt(a.p.A_diagonal[((size_t)k * D + l) * D + l], a.kc, a.qrng, 0);
             }
         }
         if (a.loss != nullptr) a.loss[b] = lossv;
@@ -521,79 +539,96 @@ __device__ __forceinline__ void adam_apply(float* var, float* m, float* v, float
     *var = *var - (m2 * alpha) / (sqrtf(v2) + a.eps);
 }
 
+// Everything one kernel contributes to the step: its variables raw and as the graph sees them, and the gradients
+// w.r.t. the (fake-quantised) graph variables incl. the l1 terms, before the backward of the fake-quant ops.
 template <int D, int C>
-__global__ void shared_adam_kernel(SharedAdamArgs a) {
+struct KernelStep {
+    float pi_raw, pi, mu_raw[D], mu[D], Araw[D][D], A[D][D], nu_raw[C], ga_raw[D * C];
+    float g_pi, g_mu[D], g_A[D][D], g_nu[C], g_ga[D * C];
+};
+
+template <int D, int C>
+__device__ __forceinline__ void kernel_step(const SharedAdamArgs& a, int k, bool clear, KernelStep<D, C>& S) {
     using L = SL<D, C>;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.K) return;
     double* rk = a.racc + (size_t)k * L::PK;
     float r[L::PK];
 #pragma unroll
-    for (int j = 0; j < L::PK; ++j) { r[j] = (float)rk[j]; rk[j] = 0.0; }
+    for (int j = 0; j < L::PK; ++j) { r[j] = (float)rk[j]; if (clear) rk[j] = 0.0; }
     const float nact = a.nact ? (float)a.nact[k] : 0.0f;
-    if (a.nact) a.nact[k] = 0.0;
-    // the gradients are those of the fake-quantised variables, passed straight through inside the nudged range
-    const float pi_raw = a.p.pis[k];
-    const float pi = fqv(pi_raw, a.kc, 3);
-    float A[D][D], Araw[D][D], mu[D], mu_raw[D];
+    if (a.nact && clear) a.nact[k] = 0.0;
+    S.pi_raw = a.p.pis[k];
+    S.pi = fqv(S.pi_raw, a.kc, 3);
 #pragma unroll
     for (int l = 0; l < D; ++l) {
-        mu_raw[l] = a.p.musX[(size_t)k * D + l];
-        mu[l] = fqv(mu_raw[l], a.kc, 1);
+        S.mu_raw[l] = a.p.musX[(size_t)k * D + l];
+        S.mu[l] = fqt(S.mu_raw[l], a.kc, a.qrng, 2);
 #pragma unroll
         for (int m = 0; m < D; ++m) {
-            Araw[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
-            A[l][m] = (l >= m) ? fqv(Araw[l][m], a.kc, 0) : 0.0f;
+            S.Araw[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+            S.A[l][m] = (l >= m) ? fqt(S.Araw[l][m], a.kc, a.qrng, (l == m) ? 0 : 1) : 0.0f;
         }
     }
+#pragma unroll
+    for (int c = 0; c < C; ++c) S.nu_raw[c] = a.p.nu_e[(size_t)k * C + c];
+#pragma unroll
+    for (int i = 0; i < D * C; ++i) S.ga_raw[i] = a.p.gamma_e[(size_t)k * D * C + i];
     const float su = r[L::R_SU];
     const bool ic = a.kc.inverse_cov != 0;        // train_inverse_cov: suz holds sum u r_l, sxz holds sum u r_l r_m
     float suz[D];
 #pragma unroll
     for (int m = 0; m < D; ++m) suz[m] = ic ? r[L::R_SUZ + m] : r[L::R_SUZ + m] * INV_SQ;
-    // pis (optimizer2)
-    if (a.train_pis) {
-        float g = (pi > 0.0f ? su / pi : 0.0f) + nact * a.reg_pi;
-        g = fq_pass(pi_raw, a.kc, 3) ? g : 0.0f;
-        adam_apply(&a.p.pis[k], &a.m.pis[k], &a.v.pis[k], g, a.lr_pis, a);
-    }
-    // musX (optimizer1)
-    if (a.train_musx) {
+    S.g_pi = (S.pi > 0.0f ? su / S.pi : 0.0f) + nact * reg_pi_of(a.reg_pi, a.kc, a.qrng);
 #pragma unroll
-        for (int l = 0; l < D; ++l) {
-            float g = 0.0f;
-            if (ic) {                             // d/dmu_l = sum_m A_lm sur_m with the symmetric A
+    for (int l = 0; l < D; ++l) {
+        float g = 0.0f;
+        if (ic) {                                 // d/dmu_l = sum_m A_lm sur_m with the symmetric A
 #pragma unroll
-                for (int m = 0; m < D; ++m) g = fmaf((l >= m) ? A[l][m] : A[m][l], suz[m], g);
-            } else {
+            for (int m = 0; m < D; ++m) g = fmaf((l >= m) ? S.A[l][m] : S.A[m][l], suz[m], g);
+        } else {
 #pragma unroll
-                for (int m = 0; m <= l; ++m) g = fmaf(A[l][m], suz[m], g);
-            }
-            g = fq_pass(mu_raw[l], a.kc, 1) ? g : 0.0f;
-            const size_t o = (size_t)k * D + l;
-            adam_apply(&a.p.musX[o], &a.m.musX[o], &a.v.musX[o], g, a.lr_expert, a);
+            for (int m = 0; m <= l; ++m) g = fmaf(S.A[l][m], suz[m], g);
         }
+        S.g_mu[l] = g;
     }
-    // steering (optimizer3)
-    float gA[D][D];
 #pragma unroll
     for (int l = 0; l < D; ++l)
 #pragma unroll
-        for (int m = 0; m <= l; ++m) {
-            float g = ic ? ((l == m) ? -0.5f * r[L::R_SXZ + tri(l, m)] : -r[L::R_SXZ + tri(l, m)])
-                         : fmaf(mu[l], suz[m], -(r[L::R_SXZ + tri(l, m)] * INV_SQ));
-            if (l == m) {
-                if (a.use_det) g += su / A[l][l];
-                g += nact * a.reg_u;
+        for (int m = 0; m < D; ++m) {
+            float g = 0.0f;
+            if (m <= l) {
+                g = ic ? ((l == m) ? -0.5f * r[L::R_SXZ + tri(l, m)] : -r[L::R_SXZ + tri(l, m)])
+                       : fmaf(S.mu[l], suz[m], -(r[L::R_SXZ + tri(l, m)] * INV_SQ));
+                if (l == m) {
+                    if (a.use_det) g += su / S.A[l][l];
+                    g += nact * a.reg_u;
+                }
             }
-            gA[l][m] = fq_pass(Araw[l][m], a.kc, 0) ? g : 0.0f;
+            S.g_A[l][m] = g;
         }
+#pragma unroll
+    for (int c = 0; c < C; ++c) S.g_nu[c] = r[L::R_SWG + c];
+#pragma unroll
+    for (int i = 0; i < D * C; ++i)              // untrained / masked slopes are constants of the graph (smoe.py:1112-1117)
+        S.g_ga[i] = (a.train_gammas && !(a.only_y_gamma && (i % C) != 0)) ? r[L::R_SWGX + i] : 0.0f;
+}
+
+// TF1 ApplyAdam on every variable of kernel k with the routed gradients in S (optimizer groups smoe.py:1102-1104)
+template <int D, int C>
+__device__ __forceinline__ void kernel_apply(const SharedAdamArgs& a, int k, KernelStep<D, C>& S) {
+    if (a.train_pis) adam_apply(&a.p.pis[k], &a.m.pis[k], &a.v.pis[k], S.g_pi, a.lr_pis, a);
+    if (a.train_musx) {
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            const size_t o = (size_t)k * D + l;
+            adam_apply(&a.p.musX[o], &a.m.musX[o], &a.v.musX[o], S.g_mu[l], a.lr_expert, a);
+        }
+    }
     if (a.kc.radial) {        // radial_as (smoe.py:714-719): one value per kernel -> its gradient is the trace; A_corr untrained
         float tr = 0.0f;
 #pragma unroll
-        for (int l = 0; l < D; ++l) tr += gA[l][l];
+        for (int l = 0; l < D; ++l) tr += S.g_A[l][l];
 #pragma unroll
-        for (int l = 0; l < D; ++l) gA[l][l] = tr;
+        for (int l = 0; l < D; ++l) S.g_A[l][l] = tr;
     }
 #pragma unroll
     for (int l = 0; l < D; ++l)
@@ -601,24 +636,188 @@ __global__ void shared_adam_kernel(SharedAdamArgs a) {
         for (int m = 0; m <= l; ++m) {
             const size_t o = ((size_t)k * D + l) * D + m;
             if (l == m) {
-                adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], gA[l][m], a.lr_steer, a);
+                adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], S.g_A[l][m], a.lr_steer, a);
             } else if (!a.kc.radial) {
-                adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], gA[l][m], a.lr_steer, a);
+                adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], S.g_A[l][m], a.lr_steer, a);
             }
         }
-    // experts (optimizer1)
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const size_t o = (size_t)k * C + c;
-        adam_apply(&a.p.nu_e[o], &a.m.nu_e[o], &a.v.nu_e[o], fq_pass(a.p.nu_e[o], a.kc, 2) ? r[L::R_SWG + c] : 0.0f, a.lr_expert, a);
+        adam_apply(&a.p.nu_e[o], &a.m.nu_e[o], &a.v.nu_e[o], S.g_nu[c], a.lr_expert, a);
     }
     if (a.train_gammas) {
 #pragma unroll
         for (int i = 0; i < D * C; ++i) {
             const size_t o = (size_t)k * D * C + i;
             if (a.only_y_gamma && (i % C) != 0) continue;
-            adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], fq_pass(a.p.gamma_e[o], a.kc, 4) ? r[L::R_SWGX + i] : 0.0f, a.lr_expert, a);
+            adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], S.g_ga[i], a.lr_expert, a);
         }
+    }
+}
+
+// quantization_mode 0 / 1 / 2 and quantize_pis: the fake-quant backward is a per-element mask (straight through inside
+// the nudged range), kernels are independent
+template <int D, int C>
+__global__ void shared_adam_kernel(SharedAdamArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.K) return;
+    KernelStep<D, C> S;
+    kernel_step<D, C>(a, k, true, S);
+    S.g_pi = fq_pass(S.pi_raw, a.kc, 3) ? S.g_pi : 0.0f;
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+        S.g_mu[l] = fq_pass(S.mu_raw[l], a.kc, 1) ? S.g_mu[l] : 0.0f;
+#pragma unroll
+        for (int m = 0; m <= l; ++m) S.g_A[l][m] = fq_pass(S.Araw[l][m], a.kc, 0) ? S.g_A[l][m] : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) S.g_nu[c] = fq_pass(S.nu_raw[c], a.kc, 2) ? S.g_nu[c] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < D * C; ++i) S.g_ga[i] = fq_pass(S.ga_raw[i], a.kc, 4) ? S.g_ga[i] : 0.0f;
+    kernel_apply<D, C>(a, k, S);
+}
+
+// ---------------------------------------------------------------------------------------------
+// image-wide records of the fake-quantised graph (SharedRangesArgs): ONE workgroup walks the kernels
+// ---------------------------------------------------------------------------------------------
+static constexpr int RG_THREADS = 1024;
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// sums (or minima) of NV per-thread values over the workgroup -> out[NV] in LDS, fixed order
+template <int NV, bool MIN>
+__device__ __forceinline__ void workgroup_reduce(float (&v)[NV], float* s_part /* [waves][NV] */, float* s_out /* [NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float t = MIN ? wave_min(v[i]) : wave_sum(v[i]);
+        if (lane == 0) s_part[wave * NV + i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float t = s_part[threadIdx.x];
+        for (int w = 1; w < waves; ++w) t = MIN ? fminf(t, s_part[w * NV + threadIdx.x]) : t + s_part[w * NV + threadIdx.x];
+        s_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+template <int D, int C>
+__device__ __forceinline__ void ranges_of_image(const smoe_params& p, int K, const KernelConsts& kc, float* qrng, float* s_part, float* s_out) {
+    constexpr float INF = __builtin_huge_valf();
+    float ex[11];                                   // lo[0..4], -hi[5..9] of this thread's kernels; [10]: -count
+#pragma unroll
+    for (int i = 0; i < 10; ++i) ex[i] = INF;
+    float cnt = 0.0f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        if (!(fqv(p.pis[k], kc, 3) > 0.0f)) continue;               // pis_mask = qpis > 0, not the kernel lists
+        cnt += 1.0f;
+        auto see = [&](int t, float x) { ex[t] = fminf(ex[t], x); ex[5 + t] = fminf(ex[5 + t], -x); };
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            see(2, p.musX[(size_t)k * D + l]);
+#pragma unroll
+            for (int m = 0; m <= l; ++m)
+                see((l == m) ? 0 : 1, (l == m) ? p.A_diagonal[((size_t)k * D + l) * D + m] : p.A_corr[((size_t)k * D + l) * D + m]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) see(3, p.nu_e[(size_t)k * C + c]);
+#pragma unroll
+        for (int i = 0; i < D * C; ++i) see(4, p.gamma_e[(size_t)k * D * C + i]);
+    }
+    float cv[1] = {cnt};
+    workgroup_reduce<1, false>(cv, s_part, s_out);
+    const float total = s_out[0];
+    __syncthreads();
+    float mv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) mv[i] = ex[i];
+    workgroup_reduce<10, true>(mv, s_part, s_out);
+    if (threadIdx.x < 5) {
+        const int t = threadIdx.x;
+        float lo = s_out[t], hi = -s_out[5 + t];
+        if (lo == INF) { lo = 0.0f; hi = 0.0f; }                       // no kernel left
+        if (t == 1) { lo = fminf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }    // diagonal / upper entries of the A_corr variable (zero)
+        const float lv = (t < 2) ? kc.q_levels[0] : ((t == 2) ? kc.q_levels[1] : ((t == 3) ? kc.q_levels[2] : kc.q_levels[4]));
+        const FqRange r = fq_vars(lo, hi, lv, t == 0 || t == 3);
+        float* o = qrng + t * 8;
+        o[0] = r.nmin; o[1] = r.nmax; o[2] = r.scale; o[3] = r.inv;
+        o[4] = r.back; o[5] = r.zero ? 1.0f : 0.0f; o[6] = lo; o[7] = hi;
+    }
+    if (threadIdx.x == 5) qrng[40] = total;
+    __threadfence();
+    __syncthreads();
+}
+
+template <int D, int C>
+__global__ void __launch_bounds__(RG_THREADS) shared_ranges_kernel(SharedRangesArgs a) {
+    __shared__ float s_part[(RG_THREADS / 64) * 20];
+    __shared__ float s_out[20];
+    ranges_of_image<D, C>(a.p, a.K, a.kc, a.qrng, s_part, s_out);
+}
+
+// quantization_mode 3: fake_quant_with_min_max_vars sends the gradient of what falls outside the nudged range to its
+// min / max input, reduce_min / reduce_max hand it to the extreme elements of the tensor (split over ties) -- an
+// image-wide exchange between the kernels.  ONE workgroup: pass 1 sums the outlying gradients and counts the ties per
+// tensor (fixed order), pass 2 routes and applies Adam.  a.qrng holds the records of the parameters BEFORE the step.
+template <int D, int C>
+__global__ void __launch_bounds__(RG_THREADS) shared_adam_routed_kernel(SharedAdamArgs a) {
+    __shared__ float s_part[(RG_THREADS / 64) * 20];
+    __shared__ float s_tot[20];
+    auto visit = [&](KernelStep<D, C>& S, auto&& f) {      // f(tensor, raw value, gradient&) over the mode-3 variables of a kernel
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+            if (a.kc.q_musx) f(2, S.mu_raw[l], S.g_mu[l]);
+#pragma unroll
+            for (int m = 0; m <= l; ++m) f((l == m) ? 0 : 1, S.Araw[l][m], S.g_A[l][m]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) f(3, S.nu_raw[c], S.g_nu[c]);
+#pragma unroll
+        for (int i = 0; i < D * C; ++i) f(4, S.ga_raw[i], S.g_ga[i]);
+    };
+    float st[20];                                   // GL[0..4], GA[5..9], ties at lo [10..14], at hi [15..19]
+#pragma unroll
+    for (int i = 0; i < 20; ++i) st[i] = 0.0f;
+    for (int k = threadIdx.x; k < a.K; k += blockDim.x) {
+        KernelStep<D, C> S;
+        kernel_step<D, C>(a, k, false, S);
+        const bool keep = S.pi > 0.0f;
+        visit(S, [&](int t, float x, float& g) {
+            const float* o = a.qrng + t * 8;
+            const float v = x - o[4];
+            const bool zero = o[5] != 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) {
+                const bool hit = tt == t;
+                st[tt] += (hit && !zero && v < o[0]) ? g : 0.0f;
+                st[5 + tt] += (hit && !zero && v > o[1]) ? g : 0.0f;
+                st[10 + tt] += (hit && keep && x == o[6]) ? 1.0f : 0.0f;
+                st[15 + tt] += (hit && keep && x == o[7]) ? 1.0f : 0.0f;
+            }
+        });
+    }
+    workgroup_reduce<20, false>(st, s_part, s_tot);
+    for (int k = threadIdx.x; k < a.K; k += blockDim.x) {
+        KernelStep<D, C> S;
+        kernel_step<D, C>(a, k, true, S);
+        const bool keep = S.pi > 0.0f;
+        S.g_pi = fq_pass(S.pi_raw, a.kc, 3) ? S.g_pi : 0.0f;
+        visit(S, [&](int t, float x, float& g) {
+            const float* o = a.qrng + t * 8;
+            const float v = x - o[4];
+            const bool zero = o[5] != 0.0f;
+            float r = (!zero && (v < o[0] || v > o[1])) ? 0.0f : g;
+            r += (keep && x == o[6]) ? s_tot[t] / fmaxf(s_tot[10 + t], 1.0f) : 0.0f;
+            r += (keep && x == o[7]) ? s_tot[5 + t] / fmaxf(s_tot[15 + t], 1.0f) : 0.0f;
+            g = r;
+        });
+        kernel_apply<D, C>(a, k, S);
     }
 }
 
@@ -635,8 +834,8 @@ __global__ void shared_readmit_kernel(SharedReadmitArgs a) {
     for (int l = 0; l < D; ++l)
 #pragma unroll
         for (int m = 0; m < D; ++m)
-            A[l][m] = (l == m) ? fqv(a.p.A_diagonal[((size_t)k * D + l) * D + m], a.kc, 0)
-                               : ((l > m) ? fqv(a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, 0) : 0.0f);
+            A[l][m] = (l == m) ? fqt(a.p.A_diagonal[((size_t)k * D + l) * D + m], a.kc, a.qrng, 0)
+                               : ((l > m) ? fqt(a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, a.qrng, 1) : 0.0f);
     int nprobe = 1;
 #pragma unroll
     for (int l = 0; l < D; ++l) nprobe *= 3;
@@ -648,7 +847,7 @@ __global__ void shared_readmit_kernel(SharedReadmitArgs a) {
         for (int l = D - 1; l >= 0; --l) {
             const int sel = rem % 3;
             rem /= 3;
-            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - fqv(a.p.musX[(size_t)k * D + l], a.kc, 1);
+            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - fqt(a.p.musX[(size_t)k * D + l], a.kc, a.qrng, 2);
         }
         float maha = 0.0f;
 #pragma unroll
@@ -730,12 +929,29 @@ hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hip
 }
 
 hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st) {
+    if (a.kc.qmode == 3) {                            // one workgroup: the fake-quant backward couples the kernels
+        if (D == 2 && C == 1) hipLaunchKernelGGL((shared_adam_routed_kernel<2, 1>), dim3(1), dim3(RG_THREADS), 0, st, a);
+        else if (D == 2 && C == 3) hipLaunchKernelGGL((shared_adam_routed_kernel<2, 3>), dim3(1), dim3(RG_THREADS), 0, st, a);
+        else if (D == 3 && C == 1) hipLaunchKernelGGL((shared_adam_routed_kernel<3, 1>), dim3(1), dim3(RG_THREADS), 0, st, a);
+        else if (D == 3 && C == 3) hipLaunchKernelGGL((shared_adam_routed_kernel<3, 3>), dim3(1), dim3(RG_THREADS), 0, st, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     const int threads = 128;
     const int grid = (a.K + threads - 1) / threads;
     if (D == 2 && C == 1) hipLaunchKernelGGL((shared_adam_kernel<2, 1>), dim3(grid), dim3(threads), 0, st, a);
     else if (D == 2 && C == 3) hipLaunchKernelGGL((shared_adam_kernel<2, 3>), dim3(grid), dim3(threads), 0, st, a);
     else if (D == 3 && C == 1) hipLaunchKernelGGL((shared_adam_kernel<3, 1>), dim3(grid), dim3(threads), 0, st, a);
     else if (D == 3 && C == 3) hipLaunchKernelGGL((shared_adam_kernel<3, 3>), dim3(grid), dim3(threads), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_shared_ranges(const SharedRangesArgs& a, int D, int C, hipStream_t st) {
+    if (D == 2 && C == 1) hipLaunchKernelGGL((shared_ranges_kernel<2, 1>), dim3(1), dim3(RG_THREADS), 0, st, a);
+    else if (D == 2 && C == 3) hipLaunchKernelGGL((shared_ranges_kernel<2, 3>), dim3(1), dim3(RG_THREADS), 0, st, a);
+    else if (D == 3 && C == 1) hipLaunchKernelGGL((shared_ranges_kernel<3, 1>), dim3(1), dim3(RG_THREADS), 0, st, a);
+    else if (D == 3 && C == 3) hipLaunchKernelGGL((shared_ranges_kernel<3, 3>), dim3(1), dim3(RG_THREADS), 0, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

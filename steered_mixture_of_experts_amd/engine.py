@@ -280,6 +280,7 @@ class SharedConfig:
     ssim_opt: bool = False
     train_inverse_cov: bool = False
     radial_as: bool = False
+    kernel_count_as_norm_l1: bool = False  # smoe.py:1022-1027: pis_l1 / count(qpis > 0) over the image
     quantization_mode: int = 0
     quantize_pis: bool = False
     bit_depths: Sequence[int] = (20, 18, 6, 10, 10)
@@ -318,6 +319,7 @@ class SharedEngine:
         c.ssim_opt = int(cfg.ssim_opt)
         c.train_inverse_cov = int(cfg.train_inverse_cov)
         c.radial_as = int(cfg.radial_as)
+        c.kernel_count_as_norm_l1 = int(cfg.kernel_count_as_norm_l1)
         c.quantization_mode, c.quantize_pis = int(cfg.quantization_mode), int(cfg.quantize_pis)
         for i in range(5):
             c.bit_depths[i] = int(cfg.bit_depths[i])

@@ -611,13 +611,13 @@ class SharedSmoe:
                  use_yuv=True, precision=8, iter_offset=0, margin=0.5, overlap_of_batches=0, device=None,
                  engine_factory=None, quantization_mode=0, quantize_pis=False, bit_depths=None, lower_bounds=None,
                  upper_bounds=None, only_y_gamma=False, use_diff_center=False, ssim_opt=False, train_inverse_cov=True,
-                 radial_as=False, loss_mask=None, **unsupported):
+                 radial_as=False, loss_mask=None, kernel_count_as_norm_l1=False, **unsupported):
         for name, val in unsupported.items():
             if val:
                 raise NotImplementedError(f"SharedSmoe({name}=...) is outside the hot path (SURVEY section 8)")
-        if quantization_mode not in (0, 1, 2):
-            raise NotImplementedError("SharedSmoe: quantization_mode 0, 1 (quantise at validation) and 2 (fixed ranges) are "
-                                      "built; mode 3 (image-wide min/max ranges) is not")
+        if quantization_mode not in (0, 1, 2, 3):
+            raise ValueError("quantization_mode must be 0, 1, 2 or 3")                # smoe_test.py:298-301
+        self.kernel_count_as_norm_l1 = bool(kernel_count_as_norm_l1)                  # smoe.py:1022-1027
         assert kernels_per_dim is not None or init_params is not None, \
             "You need to specify the kernel grid size or give initial parameters."
         image = np.asarray(image, dtype=np.float32)
@@ -639,7 +639,7 @@ class SharedSmoe:
         self.train_inverse_cov = bool(train_inverse_cov)                  # smoe.py:41: the constructor default is True
         self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
         if self.ssim_opt and (image.ndim - 1 != 2 or quantization_mode >= 2):
-            raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images, without quantization_mode 2")
+            raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images, without quantization_mode 2/3")
         self.only_y_gamma = bool(only_y_gamma) and self.use_yuv          # smoe_test.py:43-44, smoe.py:725-729
         self.use_diff_center = bool(use_diff_center)
         if quantization_mode >= 2 and use_diff_center:
@@ -726,7 +726,8 @@ class SharedSmoe:
             start_pis=self.kernels, overlap=self.overlap, quantization_mode=self.quantization_mode,
             quantize_pis=self.quantize_pis, bit_depths=tuple(self.bit_depths), lower_bounds=tuple(self.lower_bounds),
             upper_bounds=tuple(self.upper_bounds), only_y_gamma=self.only_y_gamma, ssim_opt=self.ssim_opt,
-            train_inverse_cov=self.train_inverse_cov, radial_as=self.radial_as)
+            train_inverse_cov=self.train_inverse_cov, radial_as=self.radial_as,
+            kernel_count_as_norm_l1=self.kernel_count_as_norm_l1)
         key = repr(sorted(cfg.__dict__.items()))
         if key != self._engine_key:
             if self._engine is not None:

@@ -126,13 +126,12 @@ def main(args):
                     loss_mask=loss_mask, ssim_opt=args.ssim_opt, train_inverse_cov=args.train_inverse_cov,
                     radial_as=args.radial_as, kernel_count_as_norm_l1=args.kernel_count_norm_l1, **common)
     else:
-        if args.kernel_count_norm_l1:
-            raise NotImplementedError("--mode shared: kernel_count_norm_l1 is not built")
         smoe = SharedSmoe(orig, kpd, overlap_of_batches=args.overlap_of_batches, only_y_gamma=only_y_gamma,
                           use_diff_center=args.use_diff_center, ssim_opt=args.ssim_opt, quantization_mode=args.quantization_mode,
                           quantize_pis=args.quantize_pis, bit_depths=args.bit_depths, lower_bounds=args.lower_bounds,
                           upper_bounds=args.upper_bounds, train_inverse_cov=args.train_inverse_cov,
-                          radial_as=args.radial_as, loss_mask=loss_mask, **common)
+                          radial_as=args.radial_as, loss_mask=loss_mask,
+                          kernel_count_as_norm_l1=args.kernel_count_norm_l1, **common)
     optimizer1 = Adam(args.base_lr)                                                   # smoe_test.py:84-86
     optimizer2 = Adam(args.base_lr / args.lr_div)
     optimizer3 = Adam(args.base_lr * args.lr_mult)

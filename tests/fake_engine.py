@@ -180,7 +180,8 @@ class OracleSharedEngine:
             lower_bounds=tuple(getattr(cfg, 'lower_bounds', (-2500, -.3, -5, 0, -32))),
             upper_bounds=tuple(getattr(cfg, 'upper_bounds', (2500, 1.3, 5, 2, 32))),
             only_y_gamma=getattr(cfg, 'only_y_gamma', False), ssim_opt=getattr(cfg, 'ssim_opt', False),
-            train_inverse_cov=getattr(cfg, 'train_inverse_cov', False), radial_as=getattr(cfg, 'radial_as', False))
+            train_inverse_cov=getattr(cfg, 'train_inverse_cov', False), radial_as=getattr(cfg, 'radial_as', False),
+            kernel_count_as_norm_l1=getattr(cfg, 'kernel_count_as_norm_l1', False))
         self.coords = o.global_batch_coords(cfg.image_shape, cfg.batch_shape)
         ov = int(getattr(cfg, "overlap", 0))
         self.halo = o.global_halo_coords(cfg.image_shape, cfg.batch_shape, ov) if ov > 0 else None

@@ -358,10 +358,9 @@ def test_fake_quantised_fit_through_the_facade(mode, qpis):
     assert s2.run_batched(train=False)[2] == 15
 
 
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 def test_shared_facade_with_fake_quantised_variables(mode):
-    """SharedSmoe with quantize_pis / quantization_mode 2 (smoe.py:474-496) follows oracle.shared_fit; modes 1 and 3
-    are refused in this mode."""
+    """SharedSmoe with quantize_pis / quantization_mode 2 / 3 (smoe.py:474-530) follows oracle.shared_fit."""
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import SharedSmoe
     img = _image(32, 48, seed=6)
@@ -382,9 +381,33 @@ def test_shared_facade_with_fake_quantised_variables(mode):
     for k in got:
         assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
     assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[3, 4], batch_size=[16, 16], engine_factory=OracleSharedEngine,
-                   quantization_mode=3)
+                   quantization_mode=4)
+
+
+def test_shared_facade_kernel_count_as_norm_l1():
+    """kernel_count_as_norm_l1 in the shared mode (smoe.py:1022-1027): pis_l1 is divided by the image-wide count of
+    kernels with qpis > 0 instead of start_pis."""
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    img = _image(32, 48, seed=6)
+    p0 = o.shared_init_params(img, [3, 4])
+    p0["pis"][0, 2] = 0.0004                       # rounds to 0 on the pis lattice: not counted
+    out = {}
+    for kc in (False, True):
+        s = SharedSmoe(img, train_inverse_cov=False, init_params={k: v[0].copy() for k, v in p0.items()}, batch_size=[16, 16],
+                       use_determinant=True, engine_factory=OracleSharedEngine, quantize_pis=True, kernel_count_as_norm_l1=kc)
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+        s.train(4, val_iter=2, pis_l1=0.5)
+        cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=12, lr_steer=0.01, quantize_pis=True, pis_l1=0.5,
+                             kernel_count_as_norm_l1=kc)
+        coords = o.global_batch_coords((32, 48), (16, 16))
+        tb, _ = blk.image_to_blocks(img, (16, 16))
+        pn, _, info = o.shared_fit(p0, tb.reshape(6, -1, 1), coords, cfg, 4, val_iter=2, dtype=np.float32)
+        assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
+        out[kc] = info["hist"]["loss"][0]
+    assert out[True] > out[False]                   # 11 kernels counted instead of start_pis = 12
 
 
 def test_shared_facade_only_y_gamma_and_diff_center():

@@ -279,11 +279,12 @@ def test_shared_overlap_halo(shape, bshape, C, kpd, ov):
 QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), upper_bounds=(60, 1.3, 2, 2, 4))
 
 
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 @pytest.mark.parametrize("shape,bshape,C,kpd,yuv", [CASES[0], CASES[1], CASES[3]])
 def test_shared_fake_quantised_variables(shape, bshape, C, kpd, yuv, mode):
-    """quantize_pis / quantization_mode 2 in the shared-kernel mode (smoe.py:474-496): forward, accumulated
-    gradients through the straight-through masks, one Adam step, readmission on the quantised variables."""
+    """quantize_pis / quantization_mode 2 / 3 in the shared-kernel mode (smoe.py:474-530): forward, accumulated
+    gradients through the straight-through masks (mode 3: routed to the image-wide extreme elements), one Adam
+    step, readmission on the quantised variables."""
     kw = dict(quantization_mode=mode, quantize_pis=True, **QKW)
     img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, pis_l1=0.05, u_l1=0.001, **kw)
     d = len(shape)
@@ -325,10 +326,47 @@ def test_shared_fake_quantised_variables(shape, bshape, C, kpd, yuv, mode):
     want = o.shared_readmit(got, np.zeros((NB, K), bool), coords, cfg, np.float32)
     assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want) and not want[:, 1].any()
     eng.close()
-    from steered_mixture_of_experts_amd import _lib
-    with pytest.raises(_lib.SmoeError) as e:
-        _engine(shape, bshape, C, K, yuv, quantization_mode=3)
-    assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
+    if mode == 3:
+        # what fell outside the nudged ranges went to the extreme elements: the routing moved gradient mass
+        q, back, _ = o.quantize_graph_params(p, cfg, np.float32)
+        assert any(b["below"].any() or b["above"].any() for k, b in back.items() if "below" in b)
+
+
+@pytest.mark.parametrize("kw", [dict(quantization_mode=3, quantize_pis=True, **QKW),
+                                dict(kernel_count_as_norm_l1=True, pis_l1=0.5, quantize_pis=True),
+                                dict(quantization_mode=3, quantize_pis=True, kernel_count_as_norm_l1=True, pis_l1=0.5,
+                                     train_inverse_cov=True, **QKW)])
+def test_shared_image_wide_records_follow_the_fit(kw):
+    """quantization_mode 3 (image-wide min / max ranges, gradient routing between the kernels) and
+    kernel_count_as_norm_l1 (pis_l1 / count(qpis > 0), smoe.py:1022-1027) over a short fit: the records are rebuilt
+    from the current parameters before every launch."""
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False, perturb=False, lr_steer=1e-2, **kw)
+    p["pis"][0, 5] = 0.0004            # off the lattice from the start: not counted, not in the ranges
+    if kw.get("train_inverse_cov"):
+        p["A_diagonal"] = p["A_diagonal"] ** 2
+    n = 12
+    p32, st32, i32 = o.shared_fit(p, tgt, coords, cfg, n, val_iter=6, dtype=np.float32)
+    p64, _, i64 = o.shared_fit(p, tgt, coords, cfg, n, val_iter=6, dtype=np.float64)
+    eng = _engine(shape, bshape, C, K, False, lr_steer=1e-2, **kw)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    st = eng.new_adam_state(dp)
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    hist = [float(eng.forward(T, dp, dl, want_recon=False)["loss"].mean())]
+    for _ in range(2):
+        eng.fit(T, dp, st, dl, 6)
+        eng.update_kernel_list(dp, dl)
+        hist.append(float(eng.forward(T, dp, dl, want_recon=False)["loss"].mean()))
+    torch.cuda.synchronize()
+    assert abs(hist[0] - i32["hist"]["loss"][0]) < 2e-6 * max(1.0, abs(hist[0]))
+    assert np.allclose(hist, i32["hist"]["loss"], rtol=0.02), (hist, i32["hist"]["loss"])
+    got = {k: v.cpu().numpy()[None] for k, v in dp.items()}
+    for name in o.PARAM_NAMES:
+        dev = np.median(np.abs(got[name] - p32[name]))
+        floor = np.median(np.abs(p32[name] - p64[name]))
+        assert dev <= 3 * floor + 1e-6, (name, dev, floor)
+    eng.close()
 
 
 @pytest.mark.parametrize("shape,bshape,C,kpd,yuv,ov", [((64, 64), (16, 16), 1, [4, 4], False, 0),
