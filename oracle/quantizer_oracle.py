@@ -1,6 +1,7 @@
-"""Per-block transcription of the reference's quantiser arithmetic (quantizer.py:4-145,
-utils.py:7-16), one block at a time with plain numpy -- the checker for the vectorised
-``steered_mixture_of_experts_amd.quantizer`` (test infrastructure)."""
+"""CPU restatement of the reference's parameter quantiser (quantize_params + rescaler, quantizer.py:4-145;
+reduce_params, utils.py:7-16) for ONE block at a time in plain numpy float64.  TEST INFRASTRUCTURE ONLY: the checker
+of the vectorised ``steered_mixture_of_experts_amd.quantizer``; nothing in the product imports it.  Parity unpinned
+(no reference fixtures exist for this path)."""
 import numpy as np
 
 

@@ -123,8 +123,8 @@ def test_options_outside_the_hot_path_are_refused():
     assert utils.psnr(65536.0 * 1e-3, 8) == pytest.approx(30.0)
 
 
-def test_quantizer_matches_per_block_transcription_and_mode1_training():
-    from quantizer_ref import quantize_block
+def test_quantizer_matches_per_block_restatement_and_mode1_training():
+    from oracle.quantizer_oracle import quantize_block
     from steered_mixture_of_experts_amd.quantizer import quantize_params, rescaler
     img = _image(48, 32)
     s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, quantization_mode=1,
