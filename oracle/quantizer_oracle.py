@@ -1,7 +1,8 @@
 """CPU restatement of the reference's parameter quantiser (quantize_params + rescaler, quantizer.py:4-145;
 reduce_params, utils.py:7-16) for ONE block at a time in plain numpy float64.  TEST INFRASTRUCTURE ONLY: the checker
-of the vectorised ``steered_mixture_of_experts_amd.quantizer``; nothing in the product imports it.  Parity unpinned
-(no reference fixtures exist for this path)."""
+of the vectorised ``steered_mixture_of_experts_amd.quantizer``; nothing in the product imports it.  Pinned: bit-exact
+against vectors produced by the reference's own quantize_params / rescaler (tests/golden/ref_quantizer.npz,
+tests/test_reference_golden.py)."""
 import numpy as np
 
 

@@ -5,10 +5,13 @@ TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do, and only
 as the checker / the timed CPU baseline.
 
-PARITY UNPINNED.  The reference (roljon/Steered-Mixture-of-Experts) ships no
-tests, fixtures or golden vectors, and its arithmetic lives in TensorFlow 1.x
-(version unpinned, not vendored, not installable here), so this restatement
-cannot be checked against outputs of the reference itself.  It is written from
+PARITY UNPINNED for the graph arithmetic.  The reference
+(roljon/Steered-Mixture-of-Experts) ships no tests, fixtures or golden vectors,
+and its arithmetic lives in TensorFlow 1.x (version unpinned, not vendored, not
+installable here), so the forward / gradient / Adam restatement cannot be checked
+against outputs of the reference itself.  (The host-side pieces -- coordinates,
+windows, initialisers -- ARE pinned bit-exactly against vectors produced by the
+reference's own numpy code: tests/test_reference_golden.py.)  It is written from
 the reference's source text, function by function (citations below are
 ``file:line`` under ``/root/reference``), and is cross-checked by
 ``tests/test_oracle.py`` against (i) ``torch.autograd`` on an independent

@@ -7,8 +7,30 @@ import argparse
 import os
 import re
 
-from .smoe import Smoe
+import numpy as np
+
+from . import blocks as blk
+from .smoe import SharedSmoe, Smoe
 from .utils import load_checkpoint, read_image, write_image
+
+
+def _decode_batch_shape(image_shape, channels, batches):
+    """Batch shape for decoding a whole-image (shared-kernel) model: the reference's divisor search
+    (smoe.py:2459-2543) with the smallest batch count >= ``batches`` whose batches fit the kernels' LDS tile.  Every
+    batch lists every kernel at the start (smoe.py:315), so the split does not change the reconstruction."""
+    limit = 2048 if channels == 1 else 1024
+    d = len(image_shape)
+    n = max(1, int(batches))
+    total = int(np.prod(image_shape))
+    while n <= total:
+        bs = blk.get_batch_shape(n, tuple(image_shape) + (d + channels,))[:-1]
+        if int(np.prod(bs)) <= limit:
+            return [int(b) for b in bs]
+        n = int(np.prod([s // b for s, b in zip(image_shape, bs)])) + 1
+    raise ValueError("no batch shape fits")
+
+
+_shared_engine_factory = None      # tests put the oracle-backed engine here; None = the HIP engine
 
 
 def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6, 10, 10), quant_params=False):
@@ -19,10 +41,18 @@ def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6
     init_params = cp['params']
     if results_path is not None and not os.path.exists(results_path):
         os.mkdir(results_path)
-    smoe = Smoe(orig, init_params=init_params, start_batches=batches, batch_size=list(cp['batch_size']),
-                bit_depths=list(bit_depths), precision=precision,
-                use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)),
-                train_inverse_cov=bool(cp.get('train_inverse_cov', False)))     # absent key: trained by the CLI (False)
+    common = dict(init_params=init_params, bit_depths=list(bit_depths), precision=precision,
+                  use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)),
+                  train_inverse_cov=bool(cp.get('train_inverse_cov', False)))    # absent key: trained by the CLI (False)
+    if np.asarray(init_params['pis']).ndim == 1:
+        # ONE model for the whole image = the reference's own checkpoint layout (utils.save_model, kernels leading;
+        # with reduce=True only the kernels with pis > 0) and this package's --mode shared pickles
+        d = orig.ndim - 1
+        bs = cp.get('batch_size') or _decode_batch_shape(orig.shape[:d], orig.shape[-1], batches)
+        smoe = SharedSmoe(orig, batch_size=list(bs), only_y_gamma=bool(cp.get('only_y_gamma', False)),
+                          use_diff_center=False, engine_factory=_shared_engine_factory, **common)
+    else:
+        smoe = Smoe(orig, start_batches=batches, batch_size=list(cp['batch_size']), **common)
     smoe.quantization_mode = cp.get('quantization_mode') or 0          # smoe_reconstruction.py:32-43
     smoe.quantize_pis = bool(cp.get('quantized_pis'))
     smoe.lower_bounds, smoe.upper_bounds = cp.get('lower_bounds'), cp.get('upper_bounds')
