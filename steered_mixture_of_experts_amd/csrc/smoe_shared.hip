@@ -44,10 +44,21 @@ struct SL {                                // staged (derived) record of one ker
     static constexpr int PK = R_SWGX + D * C;
 };
 
+// Sum over the 64 lanes, returned to every lane.  DPP only (no LDS round trips: __shfl_xor is a ds_bpermute per step):
+// an inclusive scan inside each 16-lane row (row_shr 1, 2, 4, 8; lanes without a source read 0), then lane 15 of rows
+// 0 / 2 is broadcast into rows 1 / 3 and lane 31 into rows 2 + 3, which leaves the total in lane 63.  Fixed order.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_src(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, ROWS == 0xf));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_src<0x111, 0xf>(v);
+    v += dpp_src<0x112, 0xf>(v);
+    v += dpp_src<0x114, 0xf>(v);
+    v += dpp_src<0x118, 0xf>(v);
+    v += dpp_src<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v += dpp_src<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
