@@ -51,6 +51,18 @@ template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_src(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, ROWS == 0xf));
 }
+// inclusive prefix sum of an int over the 64 lanes, same DPP steps (row_bcast adds the preceding rows' totals to whole rows)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_srci(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, ROWS == 0xf); }
+__device__ __forceinline__ int wave_scan(int v) {
+    v += dpp_srci<0x111, 0xf>(v);
+    v += dpp_srci<0x112, 0xf>(v);
+    v += dpp_srci<0x114, 0xf>(v);
+    v += dpp_srci<0x118, 0xf>(v);
+    v += dpp_srci<0x142, 0xa>(v);
+    v += dpp_srci<0x143, 0xc>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_src<0x111, 0xf>(v);
     v += dpp_src<0x112, 0xf>(v);
@@ -122,19 +134,34 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_cnt + 8);       // [KW]
 
     // ---- 0. compact the batch's kernel list: listed & pis > 0 (smoe.py:480,738) ----------------
+    // one thread per 32-bit word of the bitmap (the lists are sparse: only the listed kernels' priors are read), ascending
+    // kernel ids: exclusive prefix of the per-word counts inside the wavefront by DPP, across wavefronts through LDS
     const uint32_t* bits = a.lists + (size_t)b * a.KW;
     if (tid == 0) s_cnt[0] = 0;
     __syncthreads();
-    for (int base = 0; base < K; base += SH_THREADS) {
-        const int k = base + tid;
-        bool act = false;
-        if (k < K) act = ((bits[k >> 5] >> (k & 31)) & 1u) && (fqv(a.p.pis[k], a.kc, 3) > 0.0f);
-        const unsigned long long m = __ballot(act);
-        if (lane == 0) s_cnt[1 + wave] = __popcll(m);
+    for (int base = 0; base < a.KW; base += SH_THREADS) {
+        const int w = base + tid;
+        uint32_t keep = 0u;
+        if (w < a.KW) {
+            uint32_t word = bits[w];
+            if (w == a.KW - 1 && (K & 31)) word &= (1u << (K & 31)) - 1u;
+            while (word) {
+                const int j = __ffs(word) - 1;
+                word &= word - 1u;
+                if (fqv(a.p.pis[w * 32 + j], a.kc, 3) > 0.0f) keep |= 1u << j;
+            }
+        }
+        const int cnt = __popc(keep);
+        const int incl = wave_scan(cnt);
+        if (lane == 63) s_cnt[1 + wave] = incl;
         __syncthreads();
-        int off = s_cnt[0];
-        for (int w = 0; w < wave; ++w) off += s_cnt[1 + w];
-        if (act) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = k;
+        int off = s_cnt[0] + incl - cnt;
+        for (int ww = 0; ww < wave; ++ww) off += s_cnt[1 + ww];
+        while (keep) {
+            const int j = __ffs(keep) - 1;
+            keep &= keep - 1u;
+            s_list[off++] = w * 32 + j;
+        }
         __syncthreads();
         if (tid == 0) s_cnt[0] += s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4];
         __syncthreads();
