@@ -638,8 +638,8 @@ class SharedSmoe:
             raise NotImplementedError("radial_as with a quantization mode is not built")
         self.train_inverse_cov = bool(train_inverse_cov)                  # smoe.py:41: the constructor default is True
         self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
-        if self.ssim_opt and (image.ndim - 1 != 2 or quantization_mode >= 2):
-            raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images, without quantization_mode 2/3")
+        if self.ssim_opt and image.ndim - 1 != 2:
+            raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images")
         self.only_y_gamma = bool(only_y_gamma) and self.use_yuv          # smoe_test.py:43-44, smoe.py:725-729
         self.use_diff_center = bool(use_diff_center)
         if quantization_mode >= 2 and use_diff_center:

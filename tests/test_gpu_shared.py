@@ -402,6 +402,37 @@ def test_shared_ssim_loss(shape, bshape, C, kpd, yuv, ov):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_shared_ssim_loss_on_fake_quantised_variables(mode):
+    """ssim_opt together with quantization_mode 2 / 3 in the shared-kernel mode: the variables are quantised at the
+    kernels' load sites, so the SSIM instantiation sees them like the margin-loss one."""
+    shape, bshape, C, kpd, yuv = (64, 96), (32, 32), 3, [3, 5], True
+    kw = dict(quantization_mode=mode, quantize_pis=True, ssim_opt=True, **QKW)
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, yuv, **kw)
+    p["A_corr"] = p["A_corr"] * np.tril(np.ones((2, 2), np.float32), -1)
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, yuv, **kw)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True, update_lists=False)
+    torch.cuda.synchronize()
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    f64 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float64, want_grads=True, q_override=recon)
+    assert np.abs(fw["loss"].cpu().numpy() - f64["loss"]).max() < 3e-5
+    g64 = {k: v.sum(axis=0) for k, v in f64["grads"].items()}
+    st = eng.new_adam_state(dp)
+    eng.accumulate(T, dp, dl)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    bad = (np.abs(f64["w"] - 0.5 / 256) < 1e-6).any() or ((np.abs(f64["y"]) < 1e-6) | (np.abs(f64["y"] - 1) < 1e-6)).any()
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g64[name]).max() + 1e-30
+        err = np.abs(st.m[name].cpu().numpy() / 0.1 - g64[name]).max() / scale
+        assert err < (2e-3 if bad else 2e-4), (name, err)
+    eng.close()
+
+
 @pytest.mark.parametrize("shape,bshape,C,kpd,yuv,ov", [((64, 64), (16, 16), 1, [4, 4], False, 2),
                                                        ((64, 96), (32, 32), 3, [3, 5], True, 0),
                                                        ((32, 32, 8), (16, 16, 4), 3, [2, 2, 2], True, 0)])
