@@ -1656,10 +1656,17 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
         using T = Tile<D, C, K, G, WAVES>;
         if (G == 16 && (a.bh != 16 || a.bw != 16 || hoist < 1)) return hipErrorNotSupported;   // register path: 16x16 only
         const bool ic = a.kc.inverse_cov != 0;
-        auto kern = ic ? fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true, false, true> : fit_kernel<D, C, K, G, WAVES, (G == 16 ? 1 : 0), true>;
-        int hl = (G == 16) ? 1 : 0;
-        if (hoist >= 1) { kern = ic ? fit_kernel<D, C, K, G, WAVES, 1, true, false, true> : fit_kernel<D, C, K, G, WAVES, 1, true>; hl = 1; }
-        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, false);
+        const bool q = a.kc.qmode >= 2;             // all variables fake-quantised: the QUANT instantiation of the SSIM kernel
+        constexpr int H0 = (G == 16) ? 1 : 0;
+        auto kern = q ? (ic ? fit_kernel<D, C, K, G, WAVES, H0, true, true, true> : fit_kernel<D, C, K, G, WAVES, H0, true, true>)
+                      : (ic ? fit_kernel<D, C, K, G, WAVES, H0, true, false, true> : fit_kernel<D, C, K, G, WAVES, H0, true>);
+        int hl = H0;
+        if (hoist >= 1) {
+            kern = q ? (ic ? fit_kernel<D, C, K, G, WAVES, 1, true, true, true> : fit_kernel<D, C, K, G, WAVES, 1, true, true>)
+                     : (ic ? fit_kernel<D, C, K, G, WAVES, 1, true, false, true> : fit_kernel<D, C, K, G, WAVES, 1, true>);
+            hl = 1;
+        }
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, q);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1676,7 +1683,9 @@ hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
         using T = Tile<D, C, K, G, WAVES>;
         if (G == 16 && (a.bh != 16 || a.bw != 16)) return hipErrorNotSupported;
         const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw);
-        auto kern = a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, false, true> : forward_kernel<D, C, K, G, WAVES, true>;
+        const bool q = a.kc.qmode >= 2;
+        auto kern = q ? (a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, true, true> : forward_kernel<D, C, K, G, WAVES, true, true>)
+                      : (a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, false, true> : forward_kernel<D, C, K, G, WAVES, true>);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;

@@ -180,8 +180,6 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     }
     if (cfg->radial_as && cfg->quantization_mode == 3)
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built");
-    if (cfg->ssim_opt && cfg->quantization_mode >= 2)
-        return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt together with quantization_mode 2/3 is not instantiated");
     if (cfg->ssim_opt) {
         // the reference pads every axis SYMMETRIC by 5 (smoe.py:993-1003), which TF only accepts for axes of
         // at least 5 samples; 3-d blocks would need an 11^3 window over a padded time axis and are not built

@@ -81,8 +81,6 @@ class Smoe:
         if quantization_mode >= 2 and use_diff_center:
             raise NotImplementedError("fake-quantised centre OFFSETS (use_diff_center with quantization_mode 2/3) "
                                       "are not built: the engine works on absolute centres")
-        if quantization_mode >= 2 and ssim_opt:
-            raise NotImplementedError("ssim_opt together with quantization_mode 2/3 is not instantiated")
         if radial_as and quantization_mode >= 1:
             raise NotImplementedError("radial_as with a quantization mode (own range formulas, smoe.py:498-504, "
                                       "quantizer.py) is not built")

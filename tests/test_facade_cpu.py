@@ -109,8 +109,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
     for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True, "quantization_mode": 1},
-               {"quantization_mode": 3, "use_diff_center": True},
-               {"quantization_mode": 2, "ssim_opt": True}):
+               {"quantization_mode": 3, "use_diff_center": True}):
         with pytest.raises(NotImplementedError):
             Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
     with pytest.raises(AssertionError):

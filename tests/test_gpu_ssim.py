@@ -135,6 +135,54 @@ def test_ssim_gentle_fit_follows_the_restatement_and_improves_ssim():
     eng.close()
 
 
+QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), upper_bounds=(60, 1.3, 2, 2, 4))
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("shape,C,kpd,yuv", [SSIM_SHAPES[0], SSIM_SHAPES[1], SSIM_SHAPES[4]])
+def test_ssim_on_fake_quantised_variables(shape, C, kpd, yuv, mode):
+    """ssim_opt together with quantization_mode 2 / 3: the QUANT instantiation of the SSIM kernels (quantised LDS image,
+    masked / routed backward) -- loss and one-step gradients against the restatement, both tilings of 16x16 blocks."""
+    for tiling in _tilings(shape):
+        B = 21
+        kw = dict(ssim_opt=True, quantization_mode=mode, quantize_pis=True, **QKW)
+        cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 500 + C, **kw)
+        d = len(shape)
+        p["A_corr"] = p["A_corr"] * np.tril(np.ones((d, d), np.float32), -1)
+        active = np.ones((B, K), dtype=bool)
+        eng = _engine(shape, C, K, use_yuv=yuv, **kw)
+        if tiling:
+            eng.set_tiling(tiling)
+        dp = _to_dev(p)
+        act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+        T = _planar(tgt)
+        fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+        recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+        # the parameter lattice in fp32 (what TF and the kernels compute), the SSIM statistic in fp64: graph on the
+        # quantised variables, then the fake-quant backward on its gradients
+        q32, back, _ = o.quantize_graph_params(p, cfg, np.float32)
+        cfg0 = o.OracleConfig(**{**cfg.__dict__, "quantization_mode": 0, "quantize_pis": False})
+        ref64 = o.forward(q32, tgt, coords, active, cfg0, None, np.float64, want_grads=True, q_override=recon)
+        ref64["grads"] = o.route_quant_grads(ref64["grads"], back, np.float64)
+        assert np.abs(fw["loss"].cpu().numpy() - ref64["loss"]).max() < 3e-5
+        state = eng.new_adam_state(dp)
+        loss = torch.zeros(B, device="cuda")
+        eng.fit(T, dp, state, act, 1, loss_out=loss)
+        torch.cuda.synchronize()
+        tie = (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+        edge = ((np.abs(ref64["y"]) < 1e-6) | (np.abs(ref64["y"] - 1) < 1e-6)).any(axis=(1, 2))
+        clean = ~(tie | edge)
+        assert clean.sum() >= B // 2
+        assert np.abs(loss.cpu().numpy() - ref64["loss"])[clean].max() < 3e-5
+        m = _to_host(state.m)
+        for name in o.PARAM_NAMES:
+            g_ref = ref64["grads"][name][clean]
+            scale = np.abs(g_ref).max() + 1e-30
+            err = np.abs(m[name][clean] / 0.1 - g_ref).max() / scale
+            assert err < 1e-4, (name, tiling, err)
+        eng.close()
+
+
 def test_ssim_unsupported_configurations():
     from steered_mixture_of_experts_amd import _lib
     from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
