@@ -37,6 +37,13 @@ g.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
 g.train(4, val_iter=2)
 out["shared"] = {"params": g.get_params(), "losses": g.get_losses(), "recon": g.get_reconstruction(),
                  "lists": np.array(g.kernel_list_per_batch), "span": (g.lo, g.hi)}
+# the same with image-wide quantities: quantization_mode 3 ranges / routing and pis_l1 / count(qpis > 0)
+q = SharedSmoe(img, train_inverse_cov=False, kernels_per_dim=[3, 4], batch_size=[16, 16], use_determinant=True,
+               engine_factory=OracleSharedEngine, quantization_mode=3, quantize_pis=True, kernel_count_as_norm_l1=True,
+               bit_depths=[14, 12, 8, 10, 10], lower_bounds=[-60, -.3, -1, 0, -4], upper_bounds=[60, 1.3, 2, 2, 4])
+q.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+q.train(4, val_iter=2, pis_l1=0.5)
+out["shared_q3"] = {"params": q.get_params(), "losses": q.get_losses()}
 if ws == 1 or dist.get_rank() == 0:
     pickle.dump(out, open(sys.argv[2], "wb"))
 if ws > 1:
@@ -77,3 +84,7 @@ def test_two_ranks_equal_one(tmp_path):
         assert np.allclose(sa["params"][k], sb["params"][k], rtol=1e-5, atol=1e-6), k
     assert np.allclose([v for _, v in sa["losses"]], [v for _, v in sb["losses"]], rtol=1e-5)
     assert (np.abs(sa["recon"] - sb["recon"]) < 1.5 / 255).mean() > 0.999
+    qa, qb = a["shared_q3"], b["shared_q3"]
+    for k in qa["params"]:
+        assert np.allclose(qa["params"][k], qb["params"][k], rtol=1e-5, atol=1e-6), k
+    assert np.allclose([v for _, v in qa["losses"]], [v for _, v in qb["losses"]], rtol=1e-5)
