@@ -32,14 +32,16 @@ def _masked_minmax(x: np.ndarray, keep: np.ndarray):
 
 def quantize_params(smoe, params: Dict[str, np.ndarray]) -> Dict[str, object]:
     """quantizer.py:4-83 for every block.  ``params``: get_params() layout with leading B."""
-    if getattr(smoe, "radial_as", False):
-        raise NotImplementedError("radial_as is outside the hot path")
+    radial = bool(getattr(smoe, "radial_as", False))       # A_diagonal is the (B, K) vector of the radial values, no A_corr
     mode = smoe.quantization_mode
     bits = list(smoe.bit_depths)
     keep = params["pis"] > 0                                             # reduce_params
     p = {k: np.asarray(v, dtype=np.float64) for k, v in params.items()}
     lower, upper = {}, {}
-    for name in ("A_diagonal", "A_corr", "musX", "nu_e", "gamma_e"):
+    names = tuple(n for n in _BITS if not (radial and n == "A_corr"))         # quantizer.py:12-14,43-45,60-62
+    if radial and p["A_diagonal"].ndim == 4:                # engine layout (equal diagonals) -> the radial value
+        p["A_diagonal"] = p["A_diagonal"][:, :, 0, 0]
+    for name in (n for n in names if n != "pis"):
         if mode <= 1 or mode == 3:
             lower[name], upper[name] = _masked_minmax(p[name], keep)
         else:                                                            # mode 2: fixed bounds
@@ -55,7 +57,7 @@ def quantize_params(smoe, params: Dict[str, np.ndarray]) -> Dict[str, object]:
     steps = {"A": 2 ** bits[0] - 1, "musX": 2 ** bits[1] - 1, "nu_e": 2 ** bits[2] - 1,
              "pis": 2 ** bits[3] - 1, "gamma_e": 2 ** bits[4] - 1}
     q = {"lower_bounds": lower, "upper_bounds": upper, "steps": steps, "used_kernels": keep}
-    for name in _BITS:
+    for name in names:
         normalized = (p[name] - lower[name]) / (upper[name] - lower[name] + 10e-12)
         qv = np.round(normalized * steps[_STEP_NAME[name]])
         m = keep.reshape(keep.shape + (1,) * (qv.ndim - 2))
@@ -70,9 +72,13 @@ def rescaler(smoe, qparams: Dict[str, object]) -> Dict[str, np.ndarray]:
     steps, lo, hi = qparams["steps"], qparams["lower_bounds"], qparams["upper_bounds"]
     keep = qparams["used_kernels"]
     r = {}
-    for name in _BITS:
+    for name in (n for n in _BITS if n in qparams):
         r[name] = qparams[name] / steps[_STEP_NAME[name]] * (hi[name] - lo[name]) + lo[name]
     r["pis"] = np.where(keep, r["pis"], 0.0)
+    if "A_corr" not in r:                                   # radial_as (quantizer.py:128-133): A = a * I
+        d = r["musX"].shape[-1]
+        r["A_diagonal"] = r["A_diagonal"][..., None, None] * np.eye(d)
+        r["A_corr"] = np.zeros_like(r["A_diagonal"])
     out = {"A": r["A_diagonal"] + r["A_corr"], "musX": r["musX"], "nu_e": r["nu_e"], "pis": r["pis"],
            "gamma_e": r["gamma_e"], "A_diagonal": r["A_diagonal"], "A_corr": r["A_corr"]}
     if getattr(smoe, "use_diff_center", False):

@@ -136,6 +136,29 @@ def gen_quantizer():
             out.update({f"{tag}.r.{k}": v for k, v in r.items()})
             i += 1
     out["ncases"] = np.array(i)
+    # radial_as: A_diagonal is a (K,) vector, A_corr is not quantised, rescaler returns A = a * I (quantizer.py:12-14,128-133)
+    j = 0
+    for d, C, K in ((2, 1, 9), (3, 3, 8)):
+        for mode, qpis in ((0, False), (1, True), (2, True)):
+            p = {"pis": rng.uniform(-0.02, 0.4, K), "musX": rng.uniform(-0.1, 1.1, (K, d)),
+                 "A_diagonal": rng.uniform(2, 40, K), "A_corr": np.zeros((K, d, d)),
+                 "nu_e": rng.uniform(-0.2, 1.2, (K, C)), "gamma_e": rng.normal(0, 1.5, (K, d, C))}
+            p["pis"][2] = 0.0
+            smoe = types.SimpleNamespace(quantization_mode=mode, quantize_pis=qpis, radial_as=True, dim_domain=d,
+                                         image=np.zeros((4,) * d + (C,)), bit_depths=[20, 18, 6, 10, 10],
+                                         lower_bounds=[-2500, -.3, -5, 0, -32], upper_bounds=[2500, 1.3, 5, 2, 32],
+                                         use_diff_center=False)
+            raw = {k: v.copy() for k, v in p.items()}
+            q = fq["quantize_params"](smoe, p)
+            r = fq["rescaler"](smoe, q)
+            assert "A_corr" not in q
+            tag = f"rq{j}"
+            out.update({f"{tag}.mode": np.array(mode), f"{tag}.quantize_pis": np.array(qpis)})
+            out.update({f"{tag}.in.{k}": v for k, v in raw.items()})
+            out.update({f"{tag}.q.{k}": q[k] for k in ("A_diagonal", "musX", "nu_e", "pis", "gamma_e")})
+            out.update({f"{tag}.r.{k}": v for k, v in r.items()})
+            j += 1
+    out["nradial"] = np.array(j)
     mse = np.array([0.5, 12.25, 650.0, 4000.0])
     out.update({"psnr.mse": mse, "psnr.p8": fp["psnr"](mse, 8), "psnr.p10": fp["psnr"](mse, 10)})
     np.savez_compressed(os.path.join(OUT, "ref_quantizer.npz"), **out)

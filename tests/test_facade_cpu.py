@@ -108,7 +108,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
-    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True, "quantization_mode": 1},
+    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True, "quantization_mode": 3},
                {"quantization_mode": 3, "use_diff_center": True}):
         with pytest.raises(NotImplementedError):
             Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
@@ -488,6 +488,32 @@ def test_radial_steering_through_the_facade(ic):
     r = Smoe(img, init_params=got, batch_size=[16, 16], use_determinant=True, radial_as=True, train_inverse_cov=ic,
              engine_factory=OracleEngine)                    # the (K,) layout round-trips through init_params
     assert np.array_equal(r.get_reconstruction(), s.get_reconstruction())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_radial_steering_with_a_quantisation_mode(mode):
+    """radial_as with quantization_mode 1 (quantise the (K,) variable at validation, quantizer.py radial paths) and 2
+    (fixed-range fake quant inside the graph): the fit follows oracle.fit, the quantised evaluation runs."""
+    img = _image(32, 32, seed=14)
+    kw = dict(quantization_mode=mode, quantize_pis=True, bit_depths=[14, 12, 8, 10, 10], lower_bounds=[-60, -.3, -1, 0, -4],
+              upper_bounds=[60, 1.3, 2, 2, 4])
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, radial_as=True, train_inverse_cov=False,
+             engine_factory=OracleEngine, **kw)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    s.train(4, val_iter=2)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4, lr_steer=0.05, radial_as=True,
+                         quantization_mode=mode, quantize_pis=True, bit_depths=tuple(kw["bit_depths"]),
+                         lower_bounds=tuple(kw["lower_bounds"]), upper_bounds=tuple(kw["upper_bounds"]))
+    pn, _, _ = o.fit(o.init_params(tb, [2, 2]), tb.reshape(4, -1, 1), o.block_coords((16, 16)), cfg, 4, val_iter=2,
+                     dtype=np.float32)
+    got = s.get_params()
+    assert got["A_diagonal"].shape == (4, 4)
+    assert np.allclose(got["A_diagonal"], pn["A_diagonal"][:, :, 0, 0], rtol=1e-5) and not got["A_corr"].any()
+    assert s.qparams is not None and "A_corr" not in s.qparams and s.qparams["A_diagonal"].shape == (4, 4)
+    if mode == 1:
+        assert [i for i, _ in s.get_qlosses()] == [0, 2, 4]
+        assert s.rparams["A_diagonal"].shape == (4, 4, 2, 2) and not s.rparams["A_corr"].any()
 
 
 def test_shared_facade_with_the_ssim_loss():

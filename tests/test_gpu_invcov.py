@@ -203,3 +203,43 @@ def test_radial_steering(shape, C, kpd, yuv, tiling, ic):
         assert err < 5e-5, (name, err)
     assert not m["A_corr"].any()
     eng.close()
+
+
+QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), upper_bounds=(60, 1.3, 2, 2, 4))
+
+
+@pytest.mark.parametrize("tiling", [16, 64])
+def test_radial_steering_with_fixed_range_quantisation(tiling):
+    """radial_as together with quantization_mode 2 (smoe.py:481-484: the (K,) variable through a fixed-range fake quant):
+    the d tied copies quantise alike, their mask is the variable's mask, the gradient stays the trace."""
+    shape, C, kpd, yuv = (16, 16), 1, [2, 2], False
+    B, d = 19, 2
+    kw = dict(pis_l1=0.05, u_l1=0.002, radial_as=True, quantization_mode=2, quantize_pis=True, **QKW)
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 950, **kw)
+    a = np.abs(p["A_diagonal"][:, :, 0, 0])
+    a[3, 1] = 75.0                                     # outside the fixed range: clamped, no gradient
+    p["A_diagonal"] = (a[..., None, None] * np.eye(d)).astype(np.float32)
+    p["A_corr"] = np.zeros_like(p["A_corr"])
+    active = np.ones((B, K), bool)
+    eng = _engine(shape, C, K, use_yuv=yuv, **kw)
+    eng.set_tiling(tiling)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    recon = np.transpose(eng.forward(T, dp, act, want_recon=True, update_active=False)["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True, q_override=recon)
+    st = eng.new_adam_state(dp)
+    eng.fit(T, dp, st, act, 1)
+    torch.cuda.synchronize()
+    tie = (np.abs(ref["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    edge = ((np.abs(ref["y"]) < 1e-6) | (np.abs(ref["y"] - 1) < 1e-6)).any(axis=(1, 2))
+    clean = ~(tie | edge)
+    m = _to_host(st.m)
+    for name in ("A_diagonal", "musX", "nu_e", "pis", "gamma_e"):
+        g_ref = ref["grads"][name][clean]
+        err = np.abs(m[name][clean] / 0.1 - g_ref).max() / (np.abs(g_ref).max() + 1e-30)
+        assert err < 5e-5, (name, err)
+    assert not m["A_corr"].any() and not m["A_diagonal"][3, 1].any()
+    dg = np.diagonal(_to_host(dp)["A_diagonal"], axis1=-2, axis2=-1)
+    assert np.all(dg == dg[..., :1])
+    eng.close()

@@ -121,6 +121,28 @@ def test_quantizer_equals_the_reference(i):
         assert np.array_equal(ro[k], QNT[f"{tag}.r.{k}"]), k
 
 
+@pytest.mark.parametrize("i", list(range(6)))
+def test_radial_quantizer_equals_the_reference(i):
+    """radial_as through quantize_params + rescaler: one steering value per kernel, no A_corr, A = a * I back."""
+    assert int(QNT["nradial"]) == 6
+    tag = f"rq{i}"
+    mode, qpis = int(QNT[f"{tag}.mode"]), bool(QNT[f"{tag}.quantize_pis"])
+    names = ("pis", "musX", "A_diagonal", "A_corr", "nu_e", "gamma_e")
+    p = {k: QNT[f"{tag}.in.{k}"] for k in names}
+    keep = p["pis"] > 0
+    smoe = types.SimpleNamespace(quantization_mode=mode, quantize_pis=qpis, radial_as=True, bit_depths=[20, 18, 6, 10, 10],
+                                 lower_bounds=[-2500, -.3, -5, 0, -32], upper_bounds=[2500, 1.3, 5, 2, 32],
+                                 use_diff_center=False)
+    q = quantizer.quantize_params(smoe, {k: v[None] for k, v in p.items()})
+    r = quantizer.rescaler(smoe, q)
+    assert "A_corr" not in q
+    for k in ("A_diagonal", "musX", "nu_e", "pis", "gamma_e"):
+        assert np.array_equal(q[k][0][keep], QNT[f"{tag}.q.{k}"]), k
+    for k in ("A", "musX", "nu_e", "pis", "gamma_e"):
+        assert np.array_equal(r[k][0][keep], QNT[f"{tag}.r.{k}"]), k
+    assert np.array_equal(r["A_diagonal"][0][keep], QNT[f"{tag}.r.A"]) and not r["A_corr"].any()
+
+
 def test_psnr_equals_the_reference():
     for prec in (8, 10):
         want = QNT[f"psnr.p{prec}"]
