@@ -90,6 +90,12 @@ def main():
                     help="diagnostic: run the constructor default (pis not fake-quantised) instead of the CLI default")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary single-image measurement")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--clock-warm-iters", type=int, default=600,
+                    help="untimed iterations on SCRATCH copies of the parameters before the W warm-up steps: the engine "
+                         "clocks of an idle MI355X take ~25 ms of load to settle (launch times 7.1, 5.3, 5.1, 4.9, 4.7, "
+                         "4.6, 4.6 ... ms, scripts/launch_times.py), a real fit runs thousands of iterations.  Runs the "
+                         "OTHER tiling of the kernel so that a kernel trace of this command averages steady launches "
+                         "only.  0 = off")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +164,22 @@ def main():
                 events.append((e0, e1, n))
             done += n
 
+    variant = eng.fit_variant(B)
+    if args.clock_warm_iters > 0:                  # scratch state: the measured trajectory starts from the same point
+        p2 = {k: v.clone() for k, v in params.items()}
+        st2 = eng.new_adam_state(p2)
+        a2, d2 = active.clone(), diverged.clone()
+        eng.set_tiling(64 if "_g16" in variant else 16)
+        if not eng.fit_variant(B):                 # no second tiling for this shape: warm with the measured kernel
+            eng.set_tiling(args.tiling)
+        left = args.clock_warm_iters
+        while left > 0:
+            eng.fit(target, p2, st2, a2, min(100, left), diverged=d2, loss0=loss0)
+            left -= 100
+        torch.cuda.synchronize()
+        eng.set_tiling(args.tiling)
+        assert eng.fit_variant(B) == variant
+        del p2, st2, a2, d2
     run_steps(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -233,7 +255,7 @@ def main():
                                    f"(= {B * N // (512 * 512)} images of 512x512), C={C}, K={K} kernels/block, "
                                    f"{args.steps} Adam iterations, CLI-default hyper-parameters",
                        "blocks_per_gpu": B, "block_shape": list(shape), "channels": C, "kernels": K,
-                       "iters_per_launch": ipl, "kernel_variant": eng.fit_variant(B),
+                       "iters_per_launch": ipl, "clock_warm_iters": args.clock_warm_iters, "kernel_variant": eng.fit_variant(B),
                        "parallelism": f"blocks sharded over {n_gpus} rank(s), no data-path collective"},
             "final_psnr_db": round(float(psnr1), 3), "initial_psnr_db": round(float(psnr0), 3),
             "final_median_block_psnr_db": round(psnr_med, 3), "diverged_blocks": n_div,

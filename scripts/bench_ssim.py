@@ -12,6 +12,7 @@ import torch
 
 from steered_mixture_of_experts_amd import blocks as blk
 from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
+from _warm import warm_block_engine
 
 
 def run(B, shape, C, kpd, iters, ssim, tiling):
@@ -26,6 +27,7 @@ def run(B, shape, C, kpd, iters, ssim, tiling):
     act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
     eng.fit(T, p, st, act, 5)
     torch.cuda.synchronize()
+    warm_block_engine(eng, T, p, act, iters=(200 if ssim else 600), other_tiling=False, restore_tiling=tiling)
     t0 = time.perf_counter()
     eng.fit(T, p, st, act, iters)
     torch.cuda.synchronize()

@@ -9,6 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from steered_mixture_of_experts_amd import blocks as blk                                    # noqa: E402
 from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig                 # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _warm import warm_block_engine                                                                       # noqa: E402
 
 
 def main():
@@ -28,6 +30,7 @@ def main():
             for _ in range(3):
                 eng.forward(T, dp, act, **kw)
             torch.cuda.synchronize()
+            warm_block_engine(eng, T, dp, act, iters=600, other_tiling=False, restore_tiling=tiling)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from steered_mixture_of_experts_amd import blocks as blk                                          # noqa: E402
 from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig, SharedConfig, SharedEngine   # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _warm import warm_block_engine, warm_shared_engine                                                                       # noqa: E402
 
 
 def block_mode(B, shape, C, kpd, reps, **kw):
@@ -25,6 +27,7 @@ def block_mode(B, shape, C, kpd, reps, **kw):
     act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
     best = {k: v.clone() for k, v in p.items()}
     bl = torch.full((B,), 1e9, device="cuda")
+    warm_block_engine(eng, T, p, act, iters=(300 if kw.get("ssim_opt") else 600))      # other tiling: its own row in the trace
     for _ in range(reps):
         out = eng.forward(T, p, act, want_recon=True, want_argmax=True, want_gate=True)
         eng.fit(T, p, st, act, 100)
