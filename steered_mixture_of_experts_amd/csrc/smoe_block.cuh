@@ -357,11 +357,15 @@ struct PixelOut {
 // EXTG (ssim_opt): dL/dq of the pixel comes from the caller (gext[c], the SSIM adjoint) instead of the
 // margin loss; the clip / fake-quant straight-through mask is still applied here and the loss slot is
 // left to the caller.
-template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false, bool IC = false>
+// FLAGS: the influence test (smoe.py:829: any w~ > 0 over the block's pixels) is kept as one wavefront-wide lane mask per
+// kernel, OR-ed on the scalar unit from the compare that feeds the mask anyway, instead of a VALU add per kernel-pixel;
+// the caller turns the masks into the S_CNT partials after its loop.
+template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false, bool IC = false, bool FLAGS = false>
 __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                       const float (&x)[D], const float (&t)[C], float lw,
                                       float* __restrict__ acc, PixelOut<D, C, K>& o,
-                                      const float* __restrict__ gext = nullptr) {
+                                      const float* __restrict__ gext = nullptr,
+                                      unsigned long long* __restrict__ flags = nullptr) {
     using Lt = Layout<D, C, K>;
     float z[K][D], g[K];
     float S = 0.0f;
@@ -405,8 +409,10 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         w[k] = g[k] * inv;
-        o.wt[k] = (w[k] > kc.tau) ? w[k] : 0.0f;
-        acc[Lt::S_CNT + k] += o.wt[k];
+        const bool infl = w[k] > kc.tau;
+        o.wt[k] = infl ? w[k] : 0.0f;
+        if constexpr (FLAGS) flags[k] |= __ballot(infl);
+        else acc[Lt::S_CNT + k] += o.wt[k];
         // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -863,9 +869,48 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
                                                  const float* __restrict__ s_lw, int N, int G, int sub,
                                                  float* __restrict__ acc) {
     const int pxl = (N + G - 1) / G;
+    // the two-dimensional three-channel instantiations keep the guarded, compiler-unrolled loop with per-pixel flag sums:
+    // interleaving two unguarded pixel steps costs them 50-60 VGPRs (d2c3k4 on 64 lanes: 196 -> 258 = one wavefront per
+    // SIMD less, -42 %); everything else gains 2-7 % from the scalar votes below
+    if constexpr (D == 2 && C == 3) {
 #pragma unroll 2
-    for (int i = 0; i < pxl; ++i) {
+        for (int i = 0; i < pxl; ++i) {
+            const int n = i * G + sub;
+            if (n < N) {
+                float x[D], t[C];
+#pragma unroll
+                for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+                const float lw = HAS_LW ? s_lw[n] : 1.0f;
+                PixelOut<D, C, K> o;
+                pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o);
+            }
+        }
+        return;
+    }
+    const int full = N / G;                        // steps in which every lane of the block has a pixel
+    unsigned long long flags[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) flags[k] = 0ull;
+    // full steps: uniform control flow, so the lane-mask votes stay on the scalar unit.  Unrolled by two by hand: the
+    // votes are convergent operations, which keeps the compiler from unrolling a loop of run-time trip count itself.
+    auto step = [&](int i) {
         const int n = i * G + sub;
+        float x[D], t[C];
+#pragma unroll
+        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+        const float lw = HAS_LW ? s_lw[n] : 1.0f;
+        PixelOut<D, C, K> o;
+        pixel<D, C, K, true, HL, false, IC, true>(R, kc, x, t, lw, acc, o, nullptr, flags);
+    };
+    int i = 0;
+    for (; i + 1 < full; i += 2) { step(i); step(i + 1); }
+    if (i < full) step(i);
+    if (full < pxl) {                              // ragged tail (N not a multiple of G): guarded, flags as partial sums
+        const int n = full * G + sub;
         if (n < N) {
             float x[D], t[C];
 #pragma unroll
@@ -877,6 +922,9 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
             pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o);
         }
     }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[Layout<D, C, K>::S_CNT + k] += ((flags[k] >> lane) & 1ull) ? 1.0f : 0.0f;
 }
 
 // HL = number of trailing axes whose index is the same for every pixel n = i*G + sub of a lane: the host
