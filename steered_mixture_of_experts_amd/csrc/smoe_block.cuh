@@ -869,26 +869,6 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
                                                  const float* __restrict__ s_lw, int N, int G, int sub,
                                                  float* __restrict__ acc) {
     const int pxl = (N + G - 1) / G;
-    // the two-dimensional three-channel instantiations keep the guarded, compiler-unrolled loop with per-pixel flag sums:
-    // interleaving two unguarded pixel steps costs them 50-60 VGPRs (d2c3k4 on 64 lanes: 196 -> 258 = one wavefront per
-    // SIMD less, -42 %); everything else gains 2-7 % from the scalar votes below
-    if constexpr (D == 2 && C == 3) {
-#pragma unroll 2
-        for (int i = 0; i < pxl; ++i) {
-            const int n = i * G + sub;
-            if (n < N) {
-                float x[D], t[C];
-#pragma unroll
-                for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
-                const float lw = HAS_LW ? s_lw[n] : 1.0f;
-                PixelOut<D, C, K> o;
-                pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o);
-            }
-        }
-        return;
-    }
     const int full = N / G;                        // steps in which every lane of the block has a pixel
     unsigned long long flags[K];
 #pragma unroll
@@ -907,8 +887,14 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
         pixel<D, C, K, true, HL, false, IC, true>(R, kc, x, t, lw, acc, o, nullptr, flags);
     };
     int i = 0;
-    for (; i + 1 < full; i += 2) { step(i); step(i + 1); }
-    if (i < full) step(i);
+    if constexpr (D == 2 && C == 3) {
+        // three channels in two dimensions: interleaving two steps costs 50-60 VGPRs (d2c3k4 on 64 lanes: 196 -> 258 = one
+        // wavefront per SIMD less), so these instantiations take one unguarded step per trip
+        for (; i < full; ++i) step(i);
+    } else {
+        for (; i + 1 < full; i += 2) { step(i); step(i + 1); }
+        if (i < full) step(i);
+    }
     if (full < pxl) {                              // ragged tail (N not a multiple of G): guarded, flags as partial sums
         const int n = full * G + sub;
         if (n < N) {
