@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "smoe_device.h"
 #include "smoe_ssim.cuh"
 #include "smoe_fq.cuh"
@@ -1166,38 +1168,48 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             if (HL > 0) hoist_const<D, C, K, HL, IC>(R, xc);
             if constexpr (SSIM) {
                 // the reference's SSIM branch does not use loss_weights (smoe.py:929-1010)
+                // Both sweeps, 16-lane tiling: the full pixel steps run unguarded (uniform control flow), a ragged tail guarded.
+                // The wavefront-per-block instantiations keep every step guarded (their three-channel versions lose up to a
+                // third to the extra register pressure otherwise).
                 const int pxl = (N + G - 1) / G;
-                for (int i = 0; i < pxl; ++i) {                 // sweep 1: reconstruction only
-                    const int n = i * G + sub;
-                    if (n < N) {
-                        float x[D], t[C], scratch_acc[Lt::NSLOT];
+                const int full = (G == 16) ? N / G : 0;
+                auto recon_step = [&](int n) {                  // sweep 1: reconstruction only
+                    float x[D], t[C], scratch_acc[Lt::NSLOT];
 #pragma unroll
-                        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+                    for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
 #pragma unroll
-                        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+                    for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
 #pragma unroll
-                        for (int j = 0; j < Lt::NSLOT; ++j) scratch_acc[j] = 0.0f;
-                        PixelOut<D, C, K> o;
-                        pixel<D, C, K, false, HL, false, IC>(R, kc, x, t, 1.0f, scratch_acc, o);
+                    for (int j = 0; j < Lt::NSLOT; ++j) scratch_acc[j] = 0.0f;
+                    PixelOut<D, C, K> o;
+                    pixel<D, C, K, false, HL, false, IC>(R, kc, x, t, 1.0f, scratch_acc, o);
 #pragma unroll
-                        for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
-                    }
-                }
+                    for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+                };
+                for (int i = 0; i < full; ++i) recon_step(i * G + sub);
+                for (int i = full; i < pxl; ++i)
+                    if (i * G + sub < N) recon_step(i * G + sub);
                 wave_lds_sync();
                 if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, true>(s_X, s_tgt, sub, wj, kc.sw);
                 else acc[Lt::S_LOSS] = ssim_block<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, kc.sw, bh, bw, N, lane);
-                for (int i = 0; i < pxl; ++i) {                 // sweep 2: forward again + backward with dL/dq
-                    const int n = i * G + sub;
-                    if (n < N) {
-                        float x[D], t[C], gq[C];
+                // sweep 2: forward again + backward with dL/dq; influence flags as scalar lane-mask votes in the full steps
+                unsigned long long flags[K];
 #pragma unroll
-                        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+                for (int k = 0; k < K; ++k) flags[k] = 0ull;
+                auto grad_step = [&](int n, auto voted) {
+                    float x[D], t[C], gq[C];
 #pragma unroll
-                        for (int c = 0; c < C; ++c) { t[c] = s_tgt[c * N + n]; gq[c] = s_X[c * N + n]; }
-                        PixelOut<D, C, K> o;
-                        pixel<D, C, K, true, HL, true, IC>(R, kc, x, t, 1.0f, acc, o, gq);
-                    }
-                }
+                    for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { t[c] = s_tgt[c * N + n]; gq[c] = s_X[c * N + n]; }
+                    PixelOut<D, C, K> o;
+                    pixel<D, C, K, true, HL, true, IC, decltype(voted)::value>(R, kc, x, t, 1.0f, acc, o, gq, flags);
+                };
+                for (int i = 0; i < full; ++i) grad_step(i * G + sub, std::true_type{});
+                for (int i = full; i < pxl; ++i)
+                    if (i * G + sub < N) grad_step(i * G + sub, std::false_type{});
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[Lt::S_CNT + k] += ((flags[k] >> lane) & 1ull) ? 1.0f : 0.0f;
             } else {
                 if (has_lw) pixel_loop_train<D, C, K, true, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
                 else pixel_loop_train<D, C, K, false, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
