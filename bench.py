@@ -269,10 +269,11 @@ def main():
         if single is not None:
             out["single_image"] = single
         if shape == (16, 16) and C == 1 and K == 4:
-            # secondary view: the kernel's real bound.  Static count from the ISA of fit_kernel<2,1,4,16,4,1>:
-            # ~126 VALU instructions per pixel in the loop (56 fma-class = 2 flop, 63 mul/add = 1 flop) plus the
-            # per-iteration phases -> ~215 fp32 flop per pixel-iteration.
-            flop_per_px_iter = 215.0
+            # secondary view: the kernel's real bound.  PMC of fit_kernel<2,1,4,16,4,1>: 2 059 VALU instructions per
+            # wavefront-iteration of 16 x 64 pixels = 129 per pixel-iteration and lane; the pixel loop is 112 instructions
+            # per step with 30 FMAs (2 flop), the per-iteration phases about a third FMAs -> ~175 fp32 flop per
+            # pixel-iteration.
+            flop_per_px_iter = 175.0
             tf = value * 1e6 * flop_per_px_iter / 1e12 / n_gpus
             out["valu"] = {"bound": "fp32 VALU issue", "flop_per_pixel_iter_est": flop_per_px_iter,
                            "achieved_tflops_per_gpu_est": round(tf, 1), "peak_tflops": 157.3,
