@@ -338,3 +338,31 @@ def test_end_to_end_fit_quality_on_a_smooth_image():
     s.train(300, val_iter=100)
     assert s.get_psnr() > q0 + 4.0, (q0, s.get_psnr())
     assert np.diagonal(s.get_params()["A_diagonal"], axis1=-2, axis2=-1).min() > 0
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """python bench.py prints ONE JSON line with the keys the driver reads, the roofline and cpu_baseline objects, and
+    times exactly the requested steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "30", "--warmup", "10",
+                          "--blocks", "4096", "--cpu-budget-s", "1.5", "--clock-warm-iters", "100"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 10 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - 4096 * 256 * 30 / (d["ms_per_step"] * 30 / 1e3) / 1e6) / d["value"] < 0.02
