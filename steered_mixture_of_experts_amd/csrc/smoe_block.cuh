@@ -889,6 +889,7 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
         pixel<D, C, K, true, HL, false, IC, true>(R, kc, x, t, lw, acc, o, nullptr, flags);
     };
     int i = 0;
+    if (full > 0) { step(0); i = 1; }              // peeled: with -fno-signed-zeros the zero initialisation of acc[] folds away
     if constexpr (D == 2 && C == 3) {
         // three channels in two dimensions: interleaving two steps costs 50-60 VGPRs (d2c3k4 on 64 lanes: 196 -> 258 = one
         // wavefront per SIMD less), so these instantiations take one unguarded step per trip
