@@ -269,8 +269,8 @@ def main():
         if single is not None:
             out["single_image"] = single
         if shape == (16, 16) and C == 1 and K == 4:
-            # secondary view: the kernel's real bound.  PMC of fit_kernel<2,1,4,16,4,1>: 2 059 VALU instructions per
-            # wavefront-iteration of 16 x 64 pixels = 129 per pixel-iteration and lane; the pixel loop is 112 instructions
+            # secondary view: the kernel's real bound.  PMC of fit_kernel<2,1,4,16,4,1>: 2 021 VALU instructions per
+            # wavefront-iteration of 16 x 64 pixels = 126 per pixel-iteration and lane; the pixel loop is 112 instructions
             # per step with 30 FMAs (2 flop), the per-iteration phases about a third FMAs -> ~175 fp32 flop per
             # pixel-iteration.
             flop_per_px_iter = 175.0
