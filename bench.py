@@ -2,84 +2,52 @@
 """bench.py -- Mpixel-iters/s of the per-block SMoE fit hot path on MI355X.
 
 A "step" is ONE training iteration (forward + analytic backward + prune + TF1 Adam) over the
-whole batch of independent 16x16 blocks, K=4 kernels, grayscale (BASELINE.json configs[1]
-shape).  The batch is ``--blocks`` synthetic blocks per GPU (default 65536 = 64 images of
-512x512), resident in HBM before the timed region.  Steps are issued as launches of
-``--iters-per-launch`` iterations (the fit kernel keeps parameters/Adam state on chip across
-the iterations of one launch).  One process per GPU; blocks are sharded across ranks with
-no data-path collective; the only collective is the 3-scalar RCCL all-reduce for the global
-loss / PSNR after the timed region.
+whole batch of independent blocks (default: 16x16, K=4 kernels, grayscale -- the BASELINE.json
+configs[1] shape).  Inputs are synthetic and resident in HBM before the timed region.  Steps are
+issued as launches of ``--iters-per-launch`` iterations (the fit kernel keeps parameters / Adam
+state on chip across the iterations of one launch).  One process per GPU; blocks are sharded
+across ranks with no data-path collective; the only collective is the 3-scalar RCCL all-reduce
+for the global loss / PSNR outside the timed region.
+
+  python bench.py                          1 GPU, 65536 blocks
+  python bench.py --gpus 8                 spawns 8 ranks itself (torch.distributed.run, RCCL)
+  python -m torch.distributed.run ... bench.py --gpus 8      the driver's own launcher: same result
+  python bench.py --gpus 8 --scaling strong --image 2160 3840 --channels 3     cfg4: ONE image split over ranks
+
+Scaling modes: ``weak`` (default) = ``--blocks`` blocks PER GPU; ``strong`` = the blocks of ONE
+``--image`` (padded to a multiple of the block) split over the ranks by ``dist.shard_range``.
 
 Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md "Measurement").
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from steered_mixture_of_experts_amd import blocks as blk            # noqa: E402
-from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIMDS = 256 * 4                # MI355X: 256 CUs x 4 SIMD-32
+ENGINE_HZ = 2.4e9              # nominal engine clock; measured under this kernel: GRBM_GUI_ACTIVE / 8 / time = 2.41 GHz
+MIN_TIMED_S = 0.05             # below this the K timed steps are repeated from cloned start state (median reported)
 
 
-def algorithmic_bytes_per_px_iter(N, K, d, C):
-    """SURVEY 8(d): the reference's boundary layout -- (d+C) fp32 per pixel fed per pass
-    (smoe.py:545) + {param, m, v} read+written once per block per iteration."""
-    P = 1 + d + 2 * d * d + d * C + C
-    return 4.0 * (d + C) + 24.0 * K * P / N
-
-
-def cpu_baseline(block_shape, C, kpd, blocks_np, n_iters, budget_s):
-    """Times the plain-C restatement (oracle/smoe_oracle.c, kind "port") on this host's cores
-    on a bounded sample of the same workload.  The only place bench.py touches oracle/."""
-    from oracle import c_oracle as co
-    from oracle import smoe_oracle as o
-    K = int(np.prod(kpd))
-    cfg = o.OracleConfig(block_shape=tuple(block_shape), channels=C, kernels=K, quantize_pis=True)   # CLI default -qp
-    threads = min(os.cpu_count() or 1, 64)
-    N = int(np.prod(block_shape))
-    coords = np.ascontiguousarray(o.block_coords(block_shape).T)
-
-    def run(nb, iters):
-        sub = blocks_np[:nb]
-        p = {k: np.ascontiguousarray(v) for k, v in blk.init_block_params(sub, kpd).items()}
-        m = {k: np.zeros_like(v) for k, v in p.items()}
-        v = {k: np.zeros_like(v) for k, v in p.items()}
-        act = np.full(nb, (1 << K) - 1, np.uint32)
-        T = blk.to_planar(sub)
-        co.forward(cfg, coords, T, p, act, want_recon=False, threads=threads)
-        bp = np.array([cfg.beta1, cfg.beta2], np.float32)
-        t0 = time.perf_counter()
-        co.fit(cfg, coords, T, p, m, v, act, iters, bp, threads=threads)
-        return time.perf_counter() - t0
-
-    cal_nb = min(len(blocks_np), 64 * threads)
-    t = run(cal_nb, 5)
-    rate = cal_nb * N * 5 / max(t, 1e-6)                     # px-iters / s
-    nb = int(min(len(blocks_np), max(threads, rate * budget_s / (N * n_iters))))
-    nb = max(threads, nb - nb % threads)
-    t = run(nb, n_iters)
-    return {"value": round(nb * N * n_iters / t / 1e6, 3), "unit": "Mpixel-iters/s", "cores": threads,
-            "kind": "port", "sample": f"{nb} of the bench blocks x {n_iters} iterations, "
-            f"oracle/smoe_oracle.c (fp32 scalar C, OpenMP over blocks), {t:.1f} s"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100,
                     help="untimed steps; the default is one full launch so that every fit launch of a default run has the same size")
-    ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=65536, help="blocks per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--image", type=int, nargs="+", default=None,
+                    help="strong scaling: image shape (H W [T]); its blocks are split over the ranks")
     ap.add_argument("--iters-per-launch", type=int, default=100)
     ap.add_argument("--tiling", type=int, default=0, help="lanes per block: 0 auto, 16, 64")
     ap.add_argument("--block-shape", type=int, nargs="+", default=[16, 16])
@@ -89,45 +57,220 @@ def main():
     ap.add_argument("--no-quantize-pis", action="store_true",
                     help="diagnostic: run the constructor default (pis not fake-quantised) instead of the CLI default")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary single-image measurement")
+    ap.add_argument("--no-reps", action="store_true", help="time the K steps once even when they take < 50 ms")
+    ap.add_argument("--max-reps", type=int, default=15)
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--clock-warm-iters", type=int, default=600,
                     help="untimed iterations on SCRATCH copies of the parameters before the W warm-up steps: the engine "
-                         "clocks of an idle MI355X take ~25 ms of load to settle (launch times 7.1, 5.3, 5.1, 4.9, 4.7, "
-                         "4.6, 4.6 ... ms, scripts/launch_times.py), a real fit runs thousands of iterations.  Runs the "
-                         "OTHER tiling of the kernel so that a kernel trace of this command averages steady launches "
-                         "only.  0 = off")
-    args = ap.parse_args()
+                         "clocks of an idle MI355X take ~25 ms of load to settle (scripts/launch_times.py); a real fit "
+                         "runs thousands of iterations.  Runs the OTHER tiling of the kernel so that a kernel trace of "
+                         "this command averages steady launches only.  0 = off")
+    ap.add_argument("--master-port", type=int, default=0, help="launcher: rendezvous port (0 = pick a free one)")
+    # test hooks (tests/test_bench_launcher.py): a CPU engine double and the gloo backend, so that the launcher and the
+    # sharding / reduction logic run without a GPU.  A line produced this way is labelled "engine" and is not a measurement.
+    ap.add_argument("--engine-factory", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment.  Runs BEFORE anything touches
+# the GPU (no torch import yet): the ranks are fresh child processes, never a re-exec of this one.
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    port = args.master_port or _free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] {args.gpus}-rank launch failed (rc {proc.returncode}, json line {'found' if line else 'missing'})",
+              file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------
+def algorithmic_bytes_per_px_iter(N, K, d, C):
+    """SURVEY 8(d): the reference's boundary layout -- (d+C) fp32 per pixel fed per pass
+    (smoe.py:545) + {param, m, v} read+written once per block per iteration."""
+    P = 1 + d + 2 * d * d + d * C + C
+    return 4.0 * (d + C) + 24.0 * K * P / N
+
+
+def synthetic_range(blk, lo, hi, shape, C, seed):
+    """Blocks [lo, hi) of a deterministic global sequence (chunks of 1024 with their own seeds), so that a strong-scaling
+    run processes the same image whatever the number of ranks."""
+    import numpy as np
+    CH = 1024
+    parts = []
+    for c in range(lo // CH, (max(hi, lo + 1) - 1) // CH + 1):
+        b = blk.synthetic_blocks(CH, shape, C, seed + 7919 * c)
+        a, e = max(lo, c * CH), min(hi, (c + 1) * CH)
+        if e > a:
+            parts.append(b[a - c * CH:e - c * CH])
+    if not parts:
+        return np.zeros((0,) + tuple(shape) + (C,), np.float32)
+    return np.ascontiguousarray(np.concatenate(parts, axis=0))
+
+
+def psnr_of(sse_blocks, N, C):
+    import numpy as np
+    sse_blocks = np.asarray(sse_blocks, np.float64)
+    agg = -10.0 * np.log10(max(sse_blocks.sum(), 1e-30) / (len(sse_blocks) * N * C))
+    med = float(np.median(-10.0 * np.log10(np.maximum(sse_blocks, 1e-12) / (N * C))))
+    return float(agg), med
+
+
+def cpu_fit_sample(blk, shape, C, kpd, sample_np, n_iters, threads, lr_steer=1.0, timed=True):
+    """Fits ``sample_np`` for n_iters iterations with the plain-C restatement (oracle/smoe_oracle.c, kind "port") and
+    evaluates it.  The only place bench.py touches oracle/ (cpu_baseline leg)."""
+    import numpy as np
+    from oracle import c_oracle as co
+    from oracle import smoe_oracle as o
+    K = int(np.prod(kpd))
+    cfg = o.OracleConfig(block_shape=tuple(shape), channels=C, kernels=K, quantize_pis=True, use_yuv=(C == 3),
+                         lr_steer=lr_steer)                                 # CLI defaults (-qp True)
+    coords = np.ascontiguousarray(o.block_coords(shape).T)
+    nb = len(sample_np)
+    p = {k: np.ascontiguousarray(v) for k, v in blk.init_block_params(sample_np, kpd).items()}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v) for k, v in p.items()}
+    act = np.full(nb, (1 << K) - 1, np.uint32)
+    T = blk.to_planar(sample_np)
+    co.forward(cfg, coords, T, p, act, want_recon=False, threads=threads)      # iteration-0 pass (prunes the lists)
+    bp = np.array([cfg.beta1, cfg.beta2], np.float32)
+    t0 = time.perf_counter()
+    co.fit(cfg, coords, T, p, m, v, act, n_iters, bp, threads=threads)
+    dt = time.perf_counter() - t0
+    f = co.forward(cfg, coords, T, p, act, want_recon=False, threads=threads)
+    return dt, f["sse"]
+
+
+def gpu_fit_sample(eng_cls, ecfg, blk, kpd, sample_np, n_iters, dev, torch):
+    """The same fit on the device engine: from the initialisation, iteration-0 pass, n_iters iterations, evaluation."""
+    eng = eng_cls(ecfg)
+    K = ecfg.kernels
+    nb = len(sample_np)
+    p = {k: torch.from_numpy(v).to(dev) for k, v in blk.init_block_params(sample_np, kpd).items()}
+    st = eng.new_adam_state(p)
+    act = torch.full((nb,), (1 << K) - 1, dtype=torch.int32, device=dev)
+    T = torch.from_numpy(blk.to_planar(sample_np)).to(dev)
+    eng.forward(T, p, act, want_recon=False)
+    done = 0
+    while done < n_iters:
+        n = min(100, n_iters - done)
+        eng.fit(T, p, st, act, n)
+        done += n
+    f = eng.forward(T, p, act, want_recon=False)
+    sse = f["sse"].cpu().numpy()
+    eng.close()
+    return sse
+
+
+def load_profile_json(name):
+    f = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(f):
+        try:
+            return json.load(open(f))
+        except Exception:
+            return {}
+    return {}
+
+
+def worker(args):
+    import numpy as np
+    import torch
+    from steered_mixture_of_experts_amd import blocks as blk
+    from steered_mixture_of_experts_amd import dist as sdist
+    from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = not args.engine_factory
+    if args.engine_factory:                          # test double (CPU); see parse_args
+        mod, attr = args.engine_factory.split(":")
+        engine_cls = getattr(__import__(mod, fromlist=[attr]), attr)
+    else:
+        engine_cls = BlockEngine
+    dist = None
     if world > 1 or os.environ.get("SMOE_BENCH_FORCE_DIST") == "1":     # the env switch exercises the RCCL path at N=1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
+    elif on_gpu:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
+    if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = world
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
 
     shape = tuple(args.block_shape)
     d, C = len(shape), args.channels
     kpd = list(args.kernels_per_dim)
     K = int(np.prod(kpd))
     N = int(np.prod(shape))
-    B = args.blocks
     use_yuv = (C == 3)
 
     # ---- synthetic inputs, resident in HBM before timing ------------------------------
-    blocks_np = blk.synthetic_blocks(B, shape, C, 20260002 + rank)
+    if args.scaling == "strong":
+        if not args.image or len(args.image) != d:
+            raise SystemExit("--scaling strong needs --image with one size per block axis")
+        grid = [-(-int(s) // b) for s, b in zip(args.image, shape)]       # padded to a multiple of the block
+        B_total = int(np.prod(grid))
+        lo, hi = sdist.shard_range(B_total, rank, world)
+        blocks_np = synthetic_range(blk, lo, hi, shape, C, 20260100)
+        workload = (f"ONE {'x'.join(map(str, args.image))} image, C={C} = {B_total} blocks of {'x'.join(map(str, shape))} "
+                    f"split over {n_gpus} rank(s)")
+    else:
+        B_total = args.blocks * world
+        lo, hi = rank * args.blocks, (rank + 1) * args.blocks
+        blocks_np = blk.synthetic_blocks(args.blocks, shape, C, 20260002 + rank)
+        workload = (f"{args.blocks} independent {'x'.join(map(str, shape))} blocks per GPU "
+                    f"(= {args.blocks * N // (512 * 512)} images of 512x512), C={C}")
+    B = len(blocks_np)
+    if B == 0:
+        raise SystemExit(f"rank {rank}: no blocks to process ({B_total} blocks over {world} ranks)")
     params_np = blk.init_block_params(blocks_np, kpd)
     # CLI defaults (smoe_test.py:262-352): -qp/--quantize_pis defaults to True, so the graph fake-quantises the pis
-    eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv,
-                                   quantize_pis=not args.no_quantize_pis))
-    if args.tiling:
+    ecfg = EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv, quantize_pis=not args.no_quantize_pis)
+    eng = engine_cls(ecfg)
+    if args.tiling and on_gpu:
         eng.set_tiling(args.tiling)
     dev = eng.device
     target = torch.from_numpy(blk.to_planar(blocks_np)).to(dev)
@@ -137,16 +280,23 @@ def main():
     diverged = torch.zeros((B,), dtype=torch.int32, device=dev)
     f0 = eng.forward(target, params, active, want_recon=False)          # iteration-0 eval pass
     loss0 = f0["loss"].clone()
-    psnr0 = None
+    sse0_blocks = f0["sse"].cpu().numpy()
+
+    def reduce3(loss, sse):
+        if on_gpu:
+            return eng.reduce_scalars(loss, sse, active)
+        act = active.numpy().view(np.uint32)
+        return torch.tensor([float(loss.double().sum()) * N, float(sse.double().sum()),
+                             float(sum(bin(int(x)).count("1") for x in act))], dtype=torch.float64)
 
     def global_scalars(loss, sse):
-        s = eng.reduce_scalars(loss, sse, active)
+        s = reduce3(loss, sse)
         if dist is not None:
             dist.all_reduce(s)                                            # RCCL, 3 doubles
         return s.cpu().numpy()
 
     s0 = global_scalars(f0["loss"], f0["sse"])
-    psnr0 = -10.0 * np.log10(s0[1] / (n_gpus * B * N * C))
+    psnr0 = -10.0 * np.log10(s0[1] / (B_total * N * C))
 
     ipl = max(1, min(args.iters_per_launch, args.steps))
 
@@ -154,18 +304,18 @@ def main():
         done = 0
         while done < k:
             n = min(ipl, k - done)
-            if events is not None:
+            if events is not None and on_gpu:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
             eng.fit(target, params, state, active, n, diverged=diverged, loss0=loss0)
-            if events is not None:
+            if events is not None and on_gpu:
                 e1.record()
                 events.append((e0, e1, n))
             done += n
 
-    variant = eng.fit_variant(B)
-    if args.clock_warm_iters > 0:                  # scratch state: the measured trajectory starts from the same point
+    variant = eng.fit_variant(B) if on_gpu else "cpu-test-double"
+    if args.clock_warm_iters > 0 and on_gpu:       # scratch state: the measured trajectory starts from the same point
         p2 = {k: v.clone() for k, v in params.items()}
         st2 = eng.new_adam_state(p2)
         a2, d2 = active.clone(), diverged.clone()
@@ -176,72 +326,121 @@ def main():
         while left > 0:
             eng.fit(target, p2, st2, a2, min(100, left), diverged=d2, loss0=loss0)
             left -= 100
-        torch.cuda.synchronize()
+        sync()
         eng.set_tiling(args.tiling)
         assert eng.fit_variant(B) == variant
         del p2, st2, a2, d2
     run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+
+    # ---- the timed region: EXACTLY K steps between barrier + synchronize, MAX over ranks.  When that is shorter than
+    # MIN_TIMED_S it is repeated from the cloned start state (same K steps, same trajectory) and the median is reported.
+    def snapshot():
+        return ({k: v.clone() for k, v in params.items()}, {k: v.clone() for k, v in state.m.items()},
+                {k: v.clone() for k, v in state.v.items()},
+                (float(state.c.beta1_power), float(state.c.beta2_power), int(state.c.step)), active.clone(), diverged.clone())
+
+    def restore(s):
+        for k in params:
+            params[k].copy_(s[0][k]); state.m[k].copy_(s[1][k]); state.v[k].copy_(s[2][k])
+        state.c.beta1_power, state.c.beta2_power, state.c.step = s[3]
+        if hasattr(state, "_step"):
+            state._step = s[3][2]
+        active.copy_(s[4]); diverged.copy_(s[5])
+
+    def timed_once(events):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps, events)
+        barrier()
+        t_local = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()), t_local
+        return t_local, t_local
+
+    start = snapshot()
     events = []
-    t0 = time.perf_counter()
-    run_steps(args.steps, events)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_wall = float(tt.item())
-    else:
-        t_wall = t_local
+    times, locals_ = [], []
+    t, tl = timed_once(events)
+    times.append(t); locals_.append(tl)
+    reps = 1
+    if t < MIN_TIMED_S and not args.no_reps:
+        reps = int(min(args.max_reps, max(3, math.ceil(4 * MIN_TIMED_S / max(t, 1e-6)))))
+        if dist is not None:                       # the same count on every rank
+            rr = torch.tensor([reps], dtype=torch.int64, device=dev)
+            dist.broadcast(rr, 0)
+            reps = int(rr.item())
+        for _ in range(reps - 1):
+            restore(start)
+            t, tl = timed_once(events)
+            times.append(t); locals_.append(tl)
+    t_wall = float(np.median(times))
+    del start
 
     # per-launch device time from HIP events on the launch stream (full-size launches only)
-    full = [e0.elapsed_time(e1) for (e0, e1, n) in events if n == ipl]
+    full = [e0.elapsed_time(e1) for (e0, e1, n) in events if n == ipl] if on_gpu else []
     launch_ms = float(np.mean(full)) if full else float("nan")
+    per_rank_ms = None
+    if dist is not None:
+        mine = torch.tensor([float(np.median(locals_)) * 1e3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(float(x.item()), 4) for x in allr]
 
     # ---- final quality (outside the timed region) --------------------------------------
     f1 = eng.forward(target, params, active, want_recon=False)
     s1 = global_scalars(f1["loss"], f1["sse"])
-    psnr1 = -10.0 * np.log10(s1[1] / (n_gpus * B * N * C))
+    psnr1 = -10.0 * np.log10(s1[1] / (B_total * N * C))
     sse_blocks = f1["sse"].cpu().numpy()
     psnr_med = float(np.median(-10.0 * np.log10(np.maximum(sse_blocks, 1e-12) / (N * C))))
     n_div = int(diverged.sum().item())
+    n_worse = int((sse_blocks > sse0_blocks * (1 + 1e-6)).sum())
+    if dist is not None:
+        cnt = torch.tensor([n_div, n_worse], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        n_div, n_worse = int(cnt[0].item()), int(cnt[1].item())
 
     # ---- secondary: BASELINE configs[1] literally (ONE 512x512 image = 1024 blocks), rank 0 only ----
     single = None
-    if rank == 0 and not args.no_extras and shape == (16, 16) and C == 1 and B >= 1024:
+    if rank == 0 and on_gpu and not args.no_extras and shape == (16, 16) and C == 1 and B >= 1024:
         Bs = 1024
         eng1 = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv, quantize_pis=True))
-        p1 = {k: torch.from_numpy(v[:Bs].copy()).to(dev) for k, v in params_np.items()}
-        st1 = eng1.new_adam_state(p1)
-        a1 = torch.full((Bs,), (1 << K) - 1, dtype=torch.int32, device=dev)
         t1 = target[:Bs].contiguous()
+
+        def fresh():
+            p1 = {k: torch.from_numpy(v[:Bs].copy()).to(dev) for k, v in params_np.items()}
+            return p1, eng1.new_adam_state(p1), torch.full((Bs,), (1 << K) - 1, dtype=torch.int32, device=dev)
+        p1, st1, a1 = fresh()
         eng1.forward(t1, p1, a1, want_recon=False)
         eng1.fit(t1, p1, st1, a1, min(20, args.steps))
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        done = 0
-        while done < args.steps:
-            n = min(ipl, args.steps - done)
-            eng1.fit(t1, p1, st1, a1, n)
-            done += n
-        e1.record()
-        torch.cuda.synchronize()
-        ms1 = e0.elapsed_time(e1)
+        ms_list = []
+        for _ in range(9):                                     # short: repeat, report the median
+            p1, st1, a1 = fresh()
+            eng1.forward(t1, p1, a1, want_recon=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            done = 0
+            while done < args.steps:
+                n = min(ipl, args.steps - done)
+                eng1.fit(t1, p1, st1, a1, n)
+                done += n
+            e1.record()
+            torch.cuda.synchronize()
+            ms_list.append(e0.elapsed_time(e1))
+        ms1 = float(np.median(ms_list))
+        bpi1 = algorithmic_bytes_per_px_iter(N, K, d, C)
+        v1 = Bs * N * args.steps / (ms1 * 1e-3) / 1e6
         single = {"workload": "one 512x512 grayscale image = 1024 blocks of 16x16, K=4 (BASELINE configs[1] literally)",
-                  "value": round(Bs * N * args.steps / (ms1 * 1e-3) / 1e6, 1), "unit": "Mpixel-iters/s",
-                  "ms_total": round(ms1, 4), "kernel_variant": eng1.fit_variant(Bs),
-                  "note": "1024 blocks cannot fill 256 CUs (1 wavefront per SIMD); the headline batch is 64 such images"}
+                  "value": round(v1, 1), "unit": "Mpixel-iters/s", "ms_total": round(ms1, 4), "reps": len(ms_list),
+                  "contract_frac": round(v1 * 1e6 * bpi1 / 1e9 / HBM_PEAK_GBS, 4),
+                  "kernel_variant": eng1.fit_variant(Bs),
+                  "note": "1024 blocks = one wavefront per SIMD at most; latency bound (DESIGN.md section 4)"}
         eng1.close()
 
     if rank == 0:
-        total_px_iters = float(n_gpus) * B * N * args.steps
+        total_px_iters = float(B_total) * N * args.steps
         value = total_px_iters / t_wall / 1e6
         bpi = algorithmic_bytes_per_px_iter(N, K, d, C)
         achieved = (B * N * ipl * bpi) / (launch_ms * 1e-3) / 1e9 if launch_ms == launch_ms else None
@@ -249,16 +448,16 @@ def main():
             "metric": "Mpixel-iters/s (SMoE fit: forward + analytic backward + TF1 Adam), 16x16 blocks / 4 kernels",
             "value": round(value, 1), "unit": "Mpixel-iters/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(t_wall * 1e3 / args.steps, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{B} independent {'x'.join(map(str, shape))} blocks per GPU "
-                                   f"(= {B * N // (512 * 512)} images of 512x512), C={C}, K={K} kernels/block, "
-                                   f"{args.steps} Adam iterations, CLI-default hyper-parameters",
-                       "blocks_per_gpu": B, "block_shape": list(shape), "channels": C, "kernels": K,
-                       "iters_per_launch": ipl, "clock_warm_iters": args.clock_warm_iters, "kernel_variant": eng.fit_variant(B),
+            "config": {"workload": f"{workload}, K={K} kernels/block, {args.steps} Adam iterations, CLI-default hyper-parameters",
+                       "total_blocks": B_total, "blocks_rank0": B, "block_shape": list(shape), "channels": C, "kernels": K,
+                       "iters_per_launch": ipl, "clock_warm_iters": args.clock_warm_iters, "kernel_variant": variant,
+                       "reps": reps, "timed_s_each_rep": [round(x, 5) for x in times],
                        "parallelism": f"blocks sharded over {n_gpus} rank(s), no data-path collective"},
             "final_psnr_db": round(float(psnr1), 3), "initial_psnr_db": round(float(psnr0), 3),
             "final_median_block_psnr_db": round(psnr_med, 3), "diverged_blocks": n_div,
+            "blocks_worse_than_initial": n_worse,
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
@@ -266,37 +465,89 @@ def main():
                          "algorithmic_bytes_per_px_iter": bpi,
                          "kernel_ms_per_launch": None if launch_ms != launch_ms else round(launch_ms, 4)},
         }
+        if args.scaling == "weak":
+            out["config"]["blocks_per_gpu"] = args.blocks
+        if dist is not None:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["per_rank_ms"] = per_rank_ms
+            out["backend"] = args.backend
+        if not on_gpu:
+            out["engine"] = args.engine_factory + " (CPU test double: NOT a measurement)"
         if single is not None:
             out["single_image"] = single
-        if shape == (16, 16) and C == 1 and K == 4:
-            # secondary view: the kernel's real bound.  PMC of fit_kernel<2,1,4,16,4,1>: 2 021 VALU instructions per
-            # wavefront-iteration of 16 x 64 pixels = 126 per pixel-iteration and lane; the pixel loop is 112 instructions
-            # per step with 30 FMAs (2 flop), the per-iteration phases about a third FMAs -> ~175 fp32 flop per
-            # pixel-iteration.
-            flop_per_px_iter = 175.0
-            tf = value * 1e6 * flop_per_px_iter / 1e12 / n_gpus
-            out["valu"] = {"bound": "fp32 VALU issue", "flop_per_pixel_iter_est": flop_per_px_iter,
-                           "achieved_tflops_per_gpu_est": round(tf, 1), "peak_tflops": 157.3,
-                           "frac_est": round(tf / 157.3, 3)}
         out["roofline"]["note"] = ("contract figure (SURVEY 8(d)): algorithmic bytes of the reference boundary layout / "
                                    "kernel time; the persistent kernel keeps the working set on chip, measured HBM "
-                                   "traffic is in 'traffic'; the real bound is fp32 VALU issue (DESIGN.md section 4)")
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                ent = tj.get(out["config"]["kernel_variant"])
-                if ent and ent.get("blocks") == B and ent.get("iters_per_launch") == ipl:
-                    out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-            except Exception:
-                pass
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(shape, C, kpd, blocks_np, args.steps, args.cpu_budget_s)
+                                   "traffic is in 'traffic'; the binding unit is fp32 VALU issue: see 'valu'")
+        # measured HBM bytes per launch: profiles/traffic.json holds, per kernel variant, the bytes that do not depend on
+        # the iteration count (staging in, parameters / slots in and out) and the bytes per iteration, both per block,
+        # from rocprofv3 FETCH_SIZE / WRITE_SIZE passes at two launch lengths (scripts/pmc_profile.sh)
+        ent = load_profile_json("traffic.json").get(variant)
+        if ent and "fixed_bytes_per_block" in ent:
+            out["roofline"]["traffic"] = int(B * (ent["fixed_bytes_per_block"] + ent["bytes_per_block_iter"] * ipl))
+            out["roofline"]["traffic_source"] = ent.get("source")
+        # the real bound: VALU issue.  profiles/pmc.json holds SQ_INSTS_VALU per pixel-iteration of the variant (PMC pass);
+        # rate = value x instructions / 64 lanes; floor = 2 cycles per wave64 instruction per SIMD-32.
+        pm = load_profile_json("pmc.json").get(variant)
+        if pm and "valu_insts_per_wave_px_iter" in pm and on_gpu:
+            ipp = pm["valu_insts_per_wave_px_iter"]              # wave-instructions per 64 pixel-iterations
+            rate = value / n_gpus * 1e6 / 64.0 * ipp             # wave-instructions / s per GPU
+            peak = SIMDS * ENGINE_HZ / 2.0
+            out["valu"] = {"bound": "fp32 VALU issue (2 cycles per wave64 instruction per SIMD-32)",
+                           "valu_insts_per_wave_px_iter": ipp, "issue_util": round(rate / peak, 4),
+                           "issue_util_profiled": pm.get("issue_util"), "source": pm.get("source")}
+        if n_gpus == 1 and not args.no_cpu_baseline and args.scaling == "weak":
+            # ---- CPU baseline (plain-C port of the restatement) on a bounded sample + the parity criterion at this step count
+            threads = min(os.cpu_count() or 1, 64)
+            cal_nb = min(B, 64 * threads)
+            dt, _ = cpu_fit_sample(blk, shape, C, kpd, blocks_np[:cal_nb], 5, threads)
+            rate = cal_nb * N * 5 / max(dt, 1e-6)
+            nb = int(min(B, max(threads, rate * args.cpu_budget_s / (N * args.steps))))
+            nb = max(threads, nb - nb % threads)
+            dt, sse_cpu = cpu_fit_sample(blk, shape, C, kpd, blocks_np[:nb], args.steps, threads)
+            cpu_agg, cpu_med = psnr_of(sse_cpu, N, C)
+            cb = {"value": round(nb * N * args.steps / dt / 1e6, 3), "unit": "Mpixel-iters/s", "cores": threads,
+                  "kind": "port", "sample": f"{nb} of the bench blocks x {args.steps} iterations, "
+                  f"oracle/smoe_oracle.c (fp32 scalar C, OpenMP over blocks), {dt:.1f} s",
+                  "final_psnr_db": round(cpu_agg, 3), "final_median_block_psnr_db": round(cpu_med, 3)}
+            out["cpu_baseline"] = cb
+            if on_gpu:
+                sse_gpu = gpu_fit_sample(BlockEngine, ecfg, blk, kpd, blocks_np[:nb], args.steps, dev, torch)
+                g_agg, g_med = psnr_of(sse_gpu, N, C)
+                out["parity"] = {"what": f"the same {nb} blocks fitted from the initialisation for {args.steps} iterations on "
+                                         "the GPU and by the CPU port, CLI-default hyper-parameters (lr_steer = 1.0)",
+                                 "gpu_final_psnr_db": round(g_agg, 3), "cpu_final_psnr_db": round(cpu_agg, 3),
+                                 "psnr_delta_db": round(g_agg - cpu_agg, 4),
+                                 "median_block_psnr_delta_db": round(g_med - cpu_med, 4),
+                                 "psnr_ok": bool(abs(g_agg - cpu_agg) <= 0.05),
+                                 "median_block_psnr_ok": bool(abs(g_med - cpu_med) <= 0.05)}
+                # well-conditioned steering step (lr_mult 10 instead of the CLI's 1000): the regime in which a PSNR is
+                # reproducible at all; 1024 blocks x 200 iterations
+                nbw = min(B, 1024)
+                ecw = EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=use_yuv, quantize_pis=True, lr_steer=1e-2)
+                _, sse_cw = cpu_fit_sample(blk, shape, C, kpd, blocks_np[:nbw], 200, threads, lr_steer=1e-2)
+                sse_gw = gpu_fit_sample(BlockEngine, ecw, blk, kpd, blocks_np[:nbw], 200, dev, torch)
+                cw, cwm = psnr_of(sse_cw, N, C)
+                gw, gwm = psnr_of(sse_gw, N, C)
+                i0, _ = psnr_of(sse0_blocks[:nbw], N, C)
+                out["well_conditioned"] = {"what": f"{nbw} blocks x 200 iterations with lr_steer = 1e-2 (lr_mult 10), GPU vs CPU port",
+                                           "initial_psnr_db": round(i0, 3),
+                                           "gpu_final_psnr_db": round(gw, 3), "cpu_final_psnr_db": round(cw, 3),
+                                           "psnr_delta_db": round(gw - cw, 4),
+                                           "median_block_psnr_delta_db": round(gwm - cwm, 4),
+                                           "psnr_ok": bool(abs(gw - cw) <= 0.05 and abs(gwm - cwm) <= 0.05)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":
