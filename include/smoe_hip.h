@@ -125,8 +125,14 @@ typedef struct smoe_context* smoe_handle;
 int smoe_create(smoe_handle* out, const smoe_config* cfg);
 int smoe_destroy(smoe_handle h);
 
-/* 1 if the (dim, channels, kernels) combination has a compiled kernel. */
+/* 1 if the (dim, channels, kernels) combination has a compiled kernel (csrc/smoe_variants.def). */
 int smoe_is_supported(int32_t dim, int32_t channels, int32_t kernels);
+
+/* The smallest instantiated kernel count >= `kernels` for (dim, channels), or -1.  The reference accepts any kernel
+ * grid (generate_kernel_grid, smoe.py:2146-2163); a caller whose count is not instantiated pads every block to this
+ * count with kernels of prior 0: `bool_mask = kernel_list & pis > 0` (smoe.py:480,738) takes them out of the graph,
+ * their gradients are 0 and ApplyAdam leaves a variable with zero slots and zero gradient where it is. */
+int smoe_padded_kernels(int32_t dim, int32_t channels, int32_t kernels);
 
 /* Copy the device-resident per-pixel coordinates [d][N] (fp32) to a HOST buffer. */
 int smoe_get_coords(smoe_handle h, float* host_out);
@@ -179,7 +185,7 @@ const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks);
 /* Resident wavefronts per CU the runtime grants smoe_fit's kernel for num_blocks (diagnostics). */
 int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks);
 
-/* Force the lanes-per-block tiling (16, 64; 0 = automatic).  Tuning / test hook. */
+/* Force the lanes-per-block tiling (16, 32, 64; 0 = automatic).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
 
 /* ---------------------------------------------------------------------------------------------

@@ -7,11 +7,21 @@ print('%-22s B=%-6d %-22s %10.1f Mpx-it/s  frac %.3f  ms/launch %.3f  psnr %.2f-
 run --blocks 65536
 run --blocks 1024
 run --blocks 1024 --tiling 16
-run --blocks 4096
+run --blocks 1024 --tiling 32
+run --blocks 2048
+run --blocks 4096 --tiling 64
+run --blocks 4096 --tiling 32
 run --blocks 4096 --tiling 16
+run --blocks 8192 --tiling 32
+run --blocks 8192 --tiling 16
+run --blocks 16384 --tiling 32
+run --blocks 16384 --tiling 16
 run --blocks 2040 --block-shape 32 32 --channels 3 --kernels-per-dim 2 4
 run --blocks 2040 --block-shape 32 32 --channels 3 --kernels-per-dim 2 4 --tiling 16
 run --blocks 32400 --channels 3
 run --blocks 32400 --channels 3 --tiling 64
+run --blocks 4050 --channels 3 --tiling 16
+run --blocks 4050 --channels 3 --tiling 32
+run --blocks 4050 --channels 3 --tiling 64
 run --blocks 65280 --block-shape 16 16 4 --channels 3 --kernels-per-dim 2 2 1
-run --blocks 65280 --block-shape 16 16 4 --channels 3 --kernels-per-dim 2 2 1 --tiling 64
+run --blocks 8160 --block-shape 16 16 4 --channels 3 --kernels-per-dim 2 2 1

@@ -20,7 +20,7 @@ SMOE_ERR_HIP = -3
 SMOE_ERR_NO_DEVICE = -4
 
 EXPORTS = (
-    "smoe_create", "smoe_destroy", "smoe_is_supported", "smoe_get_coords", "smoe_forward",
+    "smoe_create", "smoe_destroy", "smoe_is_supported", "smoe_padded_kernels", "smoe_get_coords", "smoe_forward",
     "smoe_fit", "smoe_update_kernel_list", "smoe_checkpoint_best", "smoe_reduce_scalars",
     "smoe_fit_variant", "smoe_fit_occupancy", "smoe_set_tiling", "smoe_last_error", "smoe_abi_version",
     "smoe_shared_create", "smoe_shared_destroy", "smoe_shared_num_batches", "smoe_shared_list_words",

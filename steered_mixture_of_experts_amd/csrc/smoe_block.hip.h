@@ -1,4 +1,4 @@
-// smoe_block.cuh -- CDNA4 (gfx950) device templates of the per-block SMoE hot path: packed parameter layout, the
+// smoe_block.hip.h -- CDNA4 (gfx950) device templates of the per-block SMoE hot path: packed parameter layout, the
 // per-pixel forward / backward, the LDS tile, the fit and forward kernels with their SSIM and fake-quant
 // variants, and the launcher templates.  Included by one translation unit per (D, C, K) instantiation
 // (smoe_var_*.hip), which are compiled in parallel, and by smoe_kernels.hip (small kernels + the dispatch table).
@@ -13,8 +13,8 @@
 //
 // Maths: SURVEY.md Appendix A; reference lines are cited at each step
 // (paths relative to /root/reference).
-#ifndef SMOE_BLOCK_CUH
-#define SMOE_BLOCK_CUH
+#ifndef SMOE_BLOCK_HIP_H
+#define SMOE_BLOCK_HIP_H
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,8 +22,8 @@
 #include <type_traits>
 
 #include "smoe_device.h"
-#include "smoe_ssim.cuh"
-#include "smoe_fq.cuh"
+#include "smoe_ssim.hip.h"
+#include "smoe_fq.hip.h"
 
 namespace smoe {
 
@@ -519,6 +519,9 @@ __device__ __forceinline__ void complete_const(const BlockRegs<D, C, K>& R, cons
     }
 }
 
+// (Measured dead end: the post-transform applied by the slot OWNERS to the block totals after the reduction -- each owner
+// reading the few totals / parameters its slot involves from LDS -- is 145 instructions and ~15 LDS waits per owned slot
+// with its divergent per-slot-type paths, against 124 instructions for all slots here: headline 386 -> 362 Gpx-it/s.)
 // Per-lane linear post-transform of the raw partial sums into partial gradients (all maps
 // are linear in the sums and use block-uniform parameters, so they commute with the
 // cross-lane reduction).  With suz'_m = sum u z'_m (z' = SQ z) and sxz'_lm = sum u x_l z'_m:
@@ -601,13 +604,37 @@ struct Tile {
     using Lt = Layout<D, C, K>;
     static constexpr int BPW = 64 / G;                  // blocks per wavefront
     static constexpr int NB = WAVES * BPW;              // blocks per workgroup
-    static constexpr int CH = (G == 16) ? 16 : 32;      // slots reduced per pass
+    // Cross-lane reduction geometry (reduce_slots): every lane stores its partial of slot j in row j of the wavefront's
+    // scratch (64 floats + pad); a row is read back in units of U floats, one unit per lane, RPR rows per round:
+    //   G = 16, 32: unit = the G partials of one block, lane (grp, sub) sums row `sub` of block `grp`;
+    //   G = 64    : unit = half a row, lanes 2r and 2r+1 sum the halves of row r and exchange them (DPP quad_perm).
+    static constexpr int U = (G >= 32) ? 32 : G;
+    static constexpr int RPR = U;                       // rows per round
+    static constexpr int NROUND = (Lt::NSLOT + RPR - 1) / RPR;
+    // rows of one pass = rows of the scratch: one round per pass.  (Two rounds per pass -- one LDS hand-off for 64
+    // slots -- were measured: 1 024 blocks +2 %, but the 17 KB of scratch per wavefront cost the 1 024-pixel blocks a
+    // workgroup per CU: 16x16x4 153 -> 106 Gpx-it/s.)
+    static constexpr int CH = RPR;
+    static constexpr int RPP = CH / RPR;                // rounds per pass
     static constexpr int ROW = 64 + 4;                  // padded row (bank-conflict-free b128 reads)
     static constexpr int NCHUNK = (Lt::NSLOT + CH - 1) / CH;
-    static constexpr int SPL = (Lt::NSLOT + G - 1) / G; // owned slots per lane
+    // slots owned per lane.  G = 64: both lanes of a pair hold a round's totals, lane 2r owns the slot of the even
+    // rounds, lane 2r+1 that of the odd rounds
+    static constexpr int SPL = (G == 64) ? (NROUND + 1) / 2 : NROUND;
+    __host__ __device__ static constexpr int slot_of(int sub, int s) {
+        return (G == 64) ? ((2 * s + (sub & 1)) * RPR + (sub >> 1)) : (sub + s * G);
+    }
     static constexpr int THREADS = WAVES * 64;
     static constexpr int MV_STRIDE = round_up(2 * Lt::NPAR, 4);   // Adam m,v image of one block
-
+    // Distance between the blocks of a wavefront in the target / loss-weight planes.  With 16 lanes per block the two
+    // blocks of a 32-lane group read the same LDS banks (block size = multiple of 32 floats: SQ_LDS_BANK_CONFLICT = 18 % of
+    // the LDS cycles on the headline kernel); padding the stride by 16 floats removes the conflict and was measured
+    // SLOWER (A/B in one session, three alternating runs each: 384.2 vs 371.2 Gpx-it/s) -- LDS is not the binding pipe
+    // and the unpadded planes keep the block base a multiple of 1 KB.  Kept at 0.
+    static constexpr int TGT_PAD = 0;
+    __host__ __device__ static constexpr int tgt_stride(int N) { return C * N + TGT_PAD; }
+    __host__ __device__ static constexpr int lw_stride(int N) { return N + TGT_PAD; }
+    
     // float offsets inside dynamic LDS
     // CR = coordinate rows staged in LDS (D, or D - HL when the trailing HL axes are hoisted)
     __host__ __device__ static int off_coords() { return 0; }
@@ -615,7 +642,7 @@ struct Tile {
     __host__ __device__ static int off_mv(int N, int CR) { return off_par(N, CR) + NB * Lt::LP_STRIDE; }
     __host__ __device__ static int off_scratch(int N, int CR) { return off_mv(N, CR) + NB * MV_STRIDE; }
     __host__ __device__ static int off_tgt(int N, int CR) { return off_scratch(N, CR) + WAVES * CH * ROW; }
-    __host__ __device__ static int off_lw(int N, int CR) { return off_tgt(N, CR) + NB * C * N; }
+    __host__ __device__ static int off_lw(int N, int CR) { return off_tgt(N, CR) + NB * tgt_stride(N); }
     // hq: the quantised image is only carved out when the graph is fake-quantised (fit kernels)
     __host__ __device__ static size_t bytes(int N, bool has_lw, int CR = D, bool hq = false) {
         return sizeof(float) * (size_t)off_ssim(N, has_lw, CR, hq);
@@ -626,7 +653,7 @@ struct Tile {
     static constexpr int QI_RNG = 40;
     static constexpr int QI_OUT = 12;
     static constexpr int QI_STRIDE = round_up(Lt::LP_STRIDE + QI_RNG + QI_OUT, 4);
-    __host__ __device__ static int off_qimg(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * N : 0), 4); }
+    __host__ __device__ static int off_qimg(int N, bool has_lw, int CR) { return round_up(off_lw(N, CR) + (has_lw ? NB * lw_stride(N) : 0), 4); }
     // ssim_opt (G == 64, one block per wavefront): the two tap tables of the workgroup, then per wavefront
     // the planes X [C][N] (quantised reconstruction -> dL/dq), Wa [5][N] (column sums of x, x^2, xy, y, y^2;
     // later the row pass of the adjoint) and Wb [3][N] (coefficient maps)
@@ -653,30 +680,30 @@ __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, c
         const int lb = i / per;
         const int rem = i - lb * per;
         const int b = min(blk0 + lb, B - 1);
-        s_tgt[i] = target[(size_t)b * per + rem];
+        s_tgt[lb * T::tgt_stride(N) + rem] = target[(size_t)b * per + rem];
     }
     if (loss_w != nullptr) {
         for (int i = threadIdx.x; i < T::NB * N; i += T::THREADS) {
             const int lb = i / N;
             const int rem = i - lb * N;
             const int b = min(blk0 + lb, B - 1);
-            s_lw[i] = loss_w[(size_t)b * N + rem];
+            s_lw[lb * T::lw_stride(N) + rem] = loss_w[(size_t)b * N + rem];
         }
     }
 }
 
-// Cross-lane reduction of acc[FIRST..NSLOT) over the G lanes of a block through an LDS
-// transpose: lane `sub` ends up with the totals of its slots sub, sub+G, ... in total[].
-// Pass c moves slots [c*CH, (c+1)*CH): every lane stores its partials of these slots as
-// rows (conflict-free 4-byte stores), then the owner of each row sums its G entries with
-// 16-byte reads (rows are padded by 4 floats so the b128 reads do not conflict).
+// Cross-lane reduction of acc[FIRST..NSLOT) over the G lanes of a block through an LDS transpose: the lane that owns
+// slot j = Tile::slot_of(sub, s) ends up with its total in total[s].  A pass moves CH slots: every lane stores its
+// partials of these slots as rows (conflict-free 4-byte stores); in each round every lane then sums one unit of one
+// row with 16-byte reads (rows are padded by 4 floats so the b128 reads do not conflict).  All reads of a pass are
+// issued from clamped addresses without branches, so they go out back to back behind ONE wait.
 template <int D, int C, int K, int G, int WAVES, int FIRST>
 __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, float* __restrict__ scratch_wave,
                                              int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
     using T = Tile<D, C, K, G, WAVES>;
     using Lt = Layout<D, C, K>;
-    const int grp = lane / G;
-    const int sub = lane - grp * G;
+    const int rho = (G == 64) ? (lane >> 1) : (lane % G);              // the lane's row within a round
+    const int base = (G == 64) ? (lane & 1) * T::U : (lane / G) * G;   // its unit within the row
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) total[s] = 0.0f;
 #pragma unroll
@@ -688,24 +715,35 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
             if (j >= FIRST && j < Lt::NSLOT) scratch_wave[a * T::ROW + lane] = acc[j];
         }
         wave_lds_sync();
-        {
-            constexpr int dummy = 0; (void)dummy;
-            const int s = (c * T::CH) / G;                  // which of the lane's slots lives in this pass
-            const int h = c - s * (G / T::CH);              // which CH-wide group of lanes owns rows now
-            const int a = sub - h * T::CH;
-            const int j = c * T::CH + a;
-            if (a >= 0 && a < T::CH && j >= FIRST && j < Lt::NSLOT) {
-                const float4* row = reinterpret_cast<const float4*>(scratch_wave + a * T::ROW + grp * G);
-                float4 sum = row[0];
+        float tot[T::RPP];
 #pragma unroll
-                for (int i = 1; i < G / 4; ++i) {
-                    const float4 q = row[i];
-                    sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
-                }
-                const float tot = (sum.x + sum.y) + (sum.z + sum.w);
+        for (int r = 0; r < T::RPP; ++r) {
+            const int q = c * T::RPP + r;                   // global round
+            tot[r] = 0.0f;
+            if (q * T::RPR >= Lt::NSLOT || (q + 1) * T::RPR <= FIRST) continue;       // compile-time
+            // rows past the last slot are not written: clamp the row (those sums are never used)
+            const int rows_here = (Lt::NSLOT - q * T::RPR < T::RPR) ? (Lt::NSLOT - q * T::RPR) : T::RPR;
+            const int rr = (rho < rows_here) ? rho : (rows_here - 1);
+            const float4* row = reinterpret_cast<const float4*>(scratch_wave + (r * T::RPR + rr) * T::ROW + base);
+            float4 sum = row[0];
 #pragma unroll
-                for (int ss = 0; ss < T::SPL; ++ss)
-                    if (ss == s) total[ss] = tot;
+            for (int i = 1; i < T::U / 4; ++i) {
+                const float4 v = row[i];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            tot[r] = (sum.x + sum.y) + (sum.z + sum.w);
+        }
+#pragma unroll
+        for (int r = 0; r < T::RPP; ++r) {
+            const int q = c * T::RPP + r;
+            if (q * T::RPR >= Lt::NSLOT || (q + 1) * T::RPR <= FIRST) continue;
+            float t = tot[r];
+            if (G == 64) {
+                // the other half of the row sits in the neighbouring lane: quad_perm [1,0,3,2], both lanes get the sum
+                t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));
+                if ((q & 1) == (lane & 1)) total[q >> 1] = t;
+            } else {
+                total[q] = t;
             }
         }
         wave_lds_sync();
@@ -946,8 +984,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     float* s_par = lds + T::off_par(N, CR) + lb * Lt::LP_STRIDE;
     float* s_mv = lds + T::off_mv(N, CR) + lb * T::MV_STRIDE;
     float* s_scratch = lds + T::off_scratch(N, CR) + wave * (T::CH * T::ROW);
-    const float* s_tgt = lds + T::off_tgt(N, CR) + lb * (C * N);
-    const float* s_lw = lds + T::off_lw(N, CR) + lb * N;
+    const float* s_tgt = lds + T::off_tgt(N, CR) + lb * T::tgt_stride(N);
+    const float* s_lw = lds + T::off_lw(N, CR) + lb * T::lw_stride(N);
     const bool has_lw = a.loss_w != nullptr;
 
     stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
@@ -997,7 +1035,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     }
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
-        const int j = sub + s * G;
+        const int j = T::slot_of(sub, s);
         lr[s] = reg[s] = 0.0f;
         meta[s] = -1;
         if (j < Lt::NPAR) {
@@ -1059,7 +1097,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 const FqRange rp = fq_fixed(a.kc, 3);
 #pragma unroll
                 for (int s = 0; s < T::SPL; ++s) {
-                    const int j = sub + s * G;
+                    const int j = T::slot_of(sub, s);
                     if (j < Lt::NPAR && qt[s] >= 0) {
                         const bool keep = fq_val(s_par[(meta[s] >> 4) * Lt::PK + Lt::O_PI], rp) > 0.0f;      // pis_mask = qpis > 0
                         const float x = s_par[j];
@@ -1092,7 +1130,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             // quantize_pis alone (the CLI default): the K quantised pis live in K extra floats of the block's image
 #pragma unroll
             for (int s = 0; s < T::SPL; ++s) {
-                const int j = sub + s * G;
+                const int j = T::slot_of(sub, s);
                 if (meta[s] >= 0 && (meta[s] & 15) == 0) {          // a pis slot (this branch runs with kc.qpis only)
                     const float x = s_par[j];
                     const float cl = fminf(fmaxf(x, a.kc.q_nmin[3]), a.kc.q_nmax[3]);
@@ -1105,7 +1143,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         if constexpr (QUANT) {
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
-            const int j = sub + s * G;
+            const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
                 const float x = s_par[j];
                 float q = x;
@@ -1236,7 +1274,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         float gq[T::SPL];
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
-            const int j = sub + s * G;
+            const int j = T::slot_of(sub, s);
             const int jc = (j < Lt::NPAR) ? j : 0;
             float gsum = total[s];
             if (has_reg && reg[s] != 0.0f) {
@@ -1265,7 +1303,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 const FqRange rp = fq_fixed(kc, 3);
 #pragma unroll
                 for (int s = 0; s < T::SPL; ++s) {
-                    const int j = sub + s * G;
+                    const int j = T::slot_of(sub, s);
                     bel[s] = abv[s] = tlo[s] = thi[s] = false;
                     if (j < Lt::NPAR && qt[s] >= 0) {
                         const float* o = s_rng + qt[s] * 8;
@@ -1303,7 +1341,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         bool bad = false;
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
-            const int j = sub + s * G;
+            const int j = T::slot_of(sub, s);
             const int jc = (j < Lt::NPAR) ? j : 0;
             const float pv = s_par[jc];
             const float mv = s_mv[2 * jc];
@@ -1334,7 +1372,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         wave_lds_sync();   // every lane has consumed the old flags / params
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
-            const int j = sub + s * G;
+            const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
                 s_par[j] = newp[s];
             } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
@@ -1356,7 +1394,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     if (valid_b) {
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
-            const int j = sub + s * G;
+            const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
                 int tensor, kern; long off;
                 decode_slot<D, C, K>(j, b, tensor, off, kern);
@@ -1400,8 +1438,8 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     float* s_coords = lds + T::off_coords();
     float* s_par = lds + T::off_par(N, D) + lb * Lt::LP_STRIDE;
     float* s_scratch = lds + T::off_scratch(N, D) + wave * (T::CH * T::ROW);
-    const float* s_tgt = lds + T::off_tgt(N, D) + lb * (C * N);
-    const float* s_lw = lds + T::off_lw(N, D) + lb * N;
+    const float* s_tgt = lds + T::off_tgt(N, D) + lb * T::tgt_stride(N);
+    const float* s_lw = lds + T::off_lw(N, D) + lb * T::lw_stride(N);
     const bool has_lw = a.loss_w != nullptr;
 
     stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
@@ -1425,7 +1463,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     }
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
-        const int j = sub + s * G;
+        const int j = T::slot_of(sub, s);
         if (j < Lt::NPAR) {
             int tensor, kern; long off;
             decode_slot<D, C, K>(j, b, tensor, off, kern);
@@ -1500,7 +1538,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     // publish the influence flags of the block through LDS (needed by every lane below)
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
-        const int j = sub + s * G;
+        const int j = T::slot_of(sub, s);
         if (j >= Lt::S_CNT && j < Lt::S_CNT + K) s_scratch[j - Lt::S_CNT + grp * 16] = (total[s] > 0.0f) ? 1.0f : 0.0f;
     }
     wave_lds_sync();
@@ -1511,7 +1549,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     if (valid_b) {
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
-            const int j = sub + s * G;
+            const int j = T::slot_of(sub, s);
             if (j == Lt::S_LOSS) {
                 float lossv = SSIM ? 1.0f + total[s] : total[s];
                 if (a.reg_pi != 0.0f || a.reg_u != 0.0f) {
@@ -1763,10 +1801,20 @@ int fit_occupancy(int N, bool has_lw) {
     return nb * WAVES;       // resident wavefronts per CU
 }
 
+#define SMOE_STR_(x) #x
+#define SMOE_STR(x) SMOE_STR_(x)
 #define SMOE_VARIANT(D, C, K, G, W) \
-    { D, C, K, G, W, "fit_d" #D "c" #C "k" #K "_g" #G "w" #W, &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
+    { D, C, K, G, W, "fit_d" SMOE_STR(D) "c" SMOE_STR(C) "k" SMOE_STR(K) "_g" SMOE_STR(G) "w" SMOE_STR(W), &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
       &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W>, \
       &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W>, \
+      &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W> }
+
+// Reduced instantiation for the (dim, channels, kernels) triples outside the BASELINE shapes: the margin loss with and
+// without train_inverse_cov (quantize_pis included: it lives in the default kernels); ssim_opt and quantization_mode
+// 2 / 3 are refused for these triples (smoe_capi.hip) -- each costs a further set of kernels per triple.
+#define SMOE_VARIANT_BASIC(D, C, K, G, W) \
+    { D, C, K, G, W, "fit_d" SMOE_STR(D) "c" SMOE_STR(C) "k" SMOE_STR(K) "_g" SMOE_STR(G) "w" SMOE_STR(W), &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
+      nullptr, nullptr, nullptr, &launch_readmit_quant<D, C, K, G, W>, nullptr, nullptr, \
       &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W> }
 
 }  // namespace smoe

@@ -114,19 +114,36 @@ int check_quant_config(int mode, int quantize_pis, const int32_t* bits, const fl
     return SMOE_OK;
 }
 
+// What a launch needs from a variant (the basic instantiations of smoe_variants.def lack the SSIM / mode-2,3 kernels).
+bool variant_serves(const smoe::Variant& v, const smoe_context* h) {
+    if (h->cfg.ssim_opt) return v.fit_ssim != nullptr;
+    if (h->kc.qmode) return v.fit_quant != nullptr;
+    return true;
+}
+
+// Lanes per block by batch size (measured on 16x16 blocks, profiles/r02/bench_shapes.txt): many blocks -> 16 lanes per
+// block (4 blocks per wavefront: the per-iteration work outside the pixel loop is amortised over 16 pixels per lane);
+// few blocks -> more lanes per block, so that every SIMD of the 256 CUs has wavefronts to interleave.
+// Large blocks (>= 1024 pixels) always use a whole wavefront per block: 16 lanes would leave 64+ pixels per lane, and
+// with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
+int wanted_lanes(const smoe_context* h, int num_blocks) {
+    if (h->force_g) return h->force_g;
+    if (h->N > 512) return 64;
+    if (num_blocks >= 8192) return 16;
+    if (num_blocks >= 2048) return 32;
+    return 64;
+}
+
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
-    // lanes per block: few blocks -> spread each block over a whole wavefront (more
-    // waves in flight); many blocks -> 16 lanes per block (4 blocks per wavefront, the
-    // cross-lane reduction is amortised over 4x more pixels per lane).
-    // Large blocks (>= 1024 pixels) always use a whole wavefront per block: 16 lanes would leave 64+
-    // pixels per lane, and with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
-    int want = h->force_g ? h->force_g : ((num_blocks >= 8192 && h->N <= 512) ? 16 : 64);
+    const int want = wanted_lanes(h, num_blocks);
     const smoe::Variant* fallback = nullptr;
+    int fallback_dist = 1 << 30;
     const bool hq = h->cfg.quantization_mode >= 2;     // the mode-2/3 fit kernels keep a quantised parameter image in LDS
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels) continue;
+        if (!variant_serves(v[i], h)) continue;
         if (h->cfg.ssim_opt) {
             // 16x16 blocks: the register/DPP SSIM stage on the 16-lanes-per-block tiling; any other shape: the
             // LDS stage with one block per wavefront
@@ -138,7 +155,8 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
         }
         if (v[i].lds_bytes(h->N, has_lw, hq) > 160u * 1024u) continue;
         if (v[i].G == want) return &v[i];
-        if (!fallback) fallback = &v[i];
+        const int dist = (v[i].G > want) ? (v[i].G - want) : 4 * (want - v[i].G);     // prefer the next LARGER tiling
+        if (dist < fallback_dist) { fallback = &v[i]; fallback_dist = dist; }
     }
     return h->force_g ? nullptr : fallback;
 }
@@ -156,6 +174,14 @@ int smoe_is_supported(int32_t dim, int32_t channels, int32_t kernels) {
     for (int i = 0; i < n; ++i)
         if (v[i].D == dim && v[i].C == channels && v[i].K == kernels) return 1;
     return 0;
+}
+
+int smoe_padded_kernels(int32_t dim, int32_t channels, int32_t kernels) {
+    int n = 0, best = -1;
+    const smoe::Variant* v = smoe::variants(&n);
+    for (int i = 0; i < n; ++i)
+        if (v[i].D == dim && v[i].C == channels && v[i].K >= kernels && (best < 0 || v[i].K < best)) best = v[i].K;
+    return best;
 }
 
 int smoe_create(smoe_handle* out, const smoe_config* cfg) {
@@ -282,6 +308,18 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     kc.radial = cfg->radial_as ? 1 : 0;
     kc.kcount_norm = cfg->kernel_count_as_norm_l1 ? 1 : 0;
     kc.pis_l1_raw = cfg->pis_l1;
+    {
+        int nv = 0;
+        const smoe::Variant* vv = smoe::variants(&nv);
+        bool served = false;
+        for (int i = 0; i < nv; ++i)
+            served = served || (vv[i].D == cfg->dim && vv[i].C == cfg->channels && vv[i].K == cfg->kernels && variant_serves(vv[i], h));
+        if (!served) {
+            smoe_destroy(h);
+            return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt / quantization_mode 2, 3 are built for the triples marked FULL in "
+                                              "csrc/smoe_variants.def only (add the triple there and rebuild)");
+        }
+    }
     if (cfg->ssim_opt && !find_variant(h, 1, false)) {
         smoe_destroy(h);
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt planes of this block size do not fit in LDS");
@@ -310,8 +348,8 @@ int smoe_get_coords(smoe_handle h, float* host_out) {
 
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_tiling: null handle");
-    if (lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 64)
-        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16 or 64");
+    if (lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64)
+        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32 or 64");
     h->force_g = lanes_per_block;
     return SMOE_OK;
 }

@@ -1,4 +1,4 @@
-// smoe_device.h -- argument blocks shared by the kernels (smoe_block.cuh, smoe_kernels.hip, smoe_shared.hip) and the
+// smoe_device.h -- argument blocks shared by the kernels (smoe_block.hip.h, smoe_kernels.hip, smoe_shared.hip) and the
 // C-ABI host layer (smoe_capi.hip).  Internal; the public surface is include/smoe_hip.h.
 #ifndef SMOE_DEVICE_H
 #define SMOE_DEVICE_H

@@ -1,4 +1,4 @@
-// Fake-quant helpers shared by the block kernels (smoe_block.cuh) and the shared-kernel mode (smoe_shared.hip):
+// Fake-quant helpers shared by the block kernels (smoe_block.hip.h) and the shared-kernel mode (smoe_shared.hip):
 // TF fake_quant_with_min_max_{args,vars} (smoe.py:474-538) in fp32, as the TF device kernels compute it.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,9 +1,9 @@
 // smoe_kernels.hip -- small per-block kernels (kernel-list readmission, best snapshot, scalar reduction) and the
-// dispatch table over the per-(D, C, K) instantiations of smoe_block.cuh (smoe_var_*.hip).
+// dispatch table over the per-(D, C, K) instantiations of smoe_block.hip.h (smoe_var_*.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "smoe_block.cuh"
+#include "smoe_block.hip.h"
 
 namespace smoe {
 // ---------------------------------------------------------------------------
@@ -119,21 +119,27 @@ __global__ void reduce_partials_kernel(ReduceArgs a) {
     if (threadIdx.x == 0) { a.out[0] = s[0][0]; a.out[1] = s[1][0]; a.out[2] = s[2][0]; }
 }
 
-const Variant* variants_d2c1k4();
-const Variant* variants_d2c3k4();
-const Variant* variants_d2c3k8();
-const Variant* variants_d3c3k4();
-const Variant* variants_d2c1k8();
+// one table per line of smoe_variants.def (smoe_var.hip)
+#define SMOE_TRIPLE(D, C, K, FULL) const Variant* variants_d##D##c##C##k##K(int* count);
+#include "smoe_variants.def"
+#undef SMOE_TRIPLE
 
 const Variant* variants(int* count) {
-    static Variant table[10];
-    static bool filled = false;
-    if (!filled) {
-        const Variant* parts[5] = {variants_d2c1k4(), variants_d2c3k4(), variants_d2c3k8(), variants_d3c3k4(), variants_d2c1k8()};
-        for (int i = 0; i < 5; ++i) { table[2 * i] = parts[i][0]; table[2 * i + 1] = parts[i][1]; }
-        filled = true;
+    static Variant table[256];
+    static int n = 0;
+    if (n == 0) {
+        int m = 0;
+#define SMOE_TRIPLE(D, C, K, FULL)                                   \
+        {                                                            \
+            int c = 0;                                               \
+            const Variant* part = variants_d##D##c##C##k##K(&c);     \
+            for (int i = 0; i < c && m < 256; ++i) table[m++] = part[i]; \
+        }
+#include "smoe_variants.def"
+#undef SMOE_TRIPLE
+        n = m;
     }
-    *count = 10;
+    *count = n;
     return table;
 }
 

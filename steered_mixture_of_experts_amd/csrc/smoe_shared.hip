@@ -12,8 +12,8 @@
 #include <stdint.h>
 
 #include "smoe_device.h"
-#include "smoe_ssim.cuh"
-#include "smoe_fq.cuh"
+#include "smoe_ssim.hip.h"
+#include "smoe_fq.hip.h"
 
 namespace smoe {
 
@@ -21,7 +21,7 @@ namespace {
 
 constexpr int SH_THREADS = 256;
 constexpr int SH_KC = 64;                 // kernels staged per LDS chunk
-constexpr float SQ = 0.84932180028801904272f;       // sqrt(0.5*log2(e)), see smoe_block.cuh
+constexpr float SQ = 0.84932180028801904272f;       // sqrt(0.5*log2(e)), see smoe_block.hip.h
 constexpr float INV_SQ = 1.17740022503374817543f;
 
 constexpr int tri(int l, int m) { return l * (l + 1) / 2 + m; }
@@ -110,7 +110,7 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // one pass over all batches
 // ---------------------------------------------------------------------------------------------
 // SSIM (ssim_opt, 2-d batches): loss_pixel = 1 - SSIM of the batch (smoe.py:980-1011); the quantised reconstruction and
-// the target of the batch go to LDS planes, the whole workgroup runs the SSIM stage of smoe_ssim.cuh and reads dL/dq
+// the target of the batch go to LDS planes, the whole workgroup runs the SSIM stage of smoe_ssim.hip.h and reads dL/dq
 // back for the reverse sweep.
 // IC: train_inverse_cov (compile-time, it sits in the per-pixel gate).
 template <int D, int C, int PXL, bool TRAIN, bool SSIM = false, bool IC = false>

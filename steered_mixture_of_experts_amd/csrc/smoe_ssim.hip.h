@@ -1,4 +1,4 @@
-// smoe_ssim.cuh -- the LDS SSIM stage shared by the per-block kernels (one block per wavefront) and the shared-kernel
+// smoe_ssim.hip.h -- the LDS SSIM stage shared by the per-block kernels (one block per wavefront) and the shared-kernel
 // mode (one batch per workgroup).
 #ifndef SMOE_SSIM_CUH
 #define SMOE_SSIM_CUH

@@ -122,7 +122,9 @@ def test_largest_blocks(shape, C, kpd, yuv):
 def test_refused_shapes_say_why():
     from steered_mixture_of_experts_amd import _lib
     for kw, code in ((dict(block_shape=(128, 128), channels=1, kernels=4), _lib.SMOE_ERR_INVALID),      # > 8192 pixels
-                     (dict(block_shape=(16, 16), channels=1, kernels=3), _lib.SMOE_ERR_UNSUPPORTED),   # no such instantiation
+                     (dict(block_shape=(16, 16), channels=1, kernels=5), _lib.SMOE_ERR_UNSUPPORTED),   # no such instantiation (the facade pads to 6)
+                     (dict(block_shape=(16, 16), channels=1, kernels=3, ssim_opt=True), _lib.SMOE_ERR_UNSUPPORTED),   # basic triple: margin loss only
+                     (dict(block_shape=(16, 16), channels=1, kernels=9, quantization_mode=3), _lib.SMOE_ERR_UNSUPPORTED),
                      (dict(block_shape=(4, 4), channels=1, kernels=4, ssim_opt=True), _lib.SMOE_ERR_INVALID)):
         with pytest.raises(_lib.SmoeError) as e:
             _engine(kw.pop("block_shape"), kw.pop("channels"), kw.pop("kernels"), **kw)
