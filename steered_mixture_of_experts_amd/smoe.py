@@ -10,10 +10,13 @@ axis, and every block is its own model (own [0,1]^d domain, own K kernels, own A
 returns.  All blocks are fitted by ONE kernel launch per chunk of iterations instead of one
 ``session.run`` per block per iteration (smoe.py:1643-1702).
 
-Not rebuilt here (SURVEY section 2 "OUT OF SCOPE" / section 8(f) "next"): shared global
-kernels with batch overlap, quantisation-aware fitting, SSIM loss, support vectors, motion
-models, kernel adding.  Passing those options raises NotImplementedError instead of silently
-doing something else.
+Also built: the shared-kernel image mode with batch overlap (``SharedSmoe``), the SSIM loss
+(2-d blocks), the parameter quantiser and quantisation-aware fitting (``quantization_mode`` 1-3, ``quantize_pis``),
+``train_inverse_cov``, ``radial_as``, ``use_diff_center``.  Any kernel grid is accepted: a kernel count without its own
+kernel instantiation is padded to the next instantiated one with prior-zero kernels, which the graph drops
+(``bool_mask = kernel_list & pis > 0``, smoe.py:480,738).  Not rebuilt (SURVEY section 2 "OUT OF SCOPE"): support
+vectors, motion models, kernel adding, pixel sub-sampling; passing those options raises NotImplementedError instead
+of silently doing something else.
 """
 from __future__ import annotations
 
@@ -43,6 +46,33 @@ class Adam:
 def _default_engine_factory(cfg: EngineConfig, device):
     from .engine import BlockEngine          # loads libsmoe_hip.so; fails loudly if absent
     return BlockEngine(cfg, device)
+
+
+def _default_padded_kernels(dim: int, channels: int, kernels: int) -> int:
+    """Smallest instantiated kernel count >= kernels (include/smoe_hip.h: smoe_padded_kernels)."""
+    from . import _lib
+    kp = int(_lib.load().smoe_padded_kernels(dim, channels, kernels))
+    if kp < 0:
+        raise NotImplementedError(f"no per-block kernel is instantiated for {kernels} or more kernels per block with "
+                                  f"(dim={dim}, channels={channels}); add the triple to csrc/smoe_variants.def")
+    return kp
+
+
+def _pad_kernels(p: Dict[str, np.ndarray], kp: int) -> Dict[str, np.ndarray]:
+    """Pad every block's parameter set to kp kernels with kernels that are not part of the graph: prior 0 (smoe.py:480,738:
+    bool_mask = kernel_list & pis > 0), centre 0.5, steering identity (any finite value: it is never used)."""
+    k = p["pis"].shape[1]
+    if kp == k:
+        return p
+    out = {}
+    for name, v in p.items():
+        pad = np.zeros((v.shape[0], kp - k) + v.shape[2:], dtype=np.float32)
+        if name == "musX":
+            pad[...] = 0.5
+        elif name == "A_diagonal":
+            pad[...] = np.eye(v.shape[-1], dtype=np.float32)
+        out[name] = np.ascontiguousarray(np.concatenate([v, pad], axis=1))
+    return out
 
 
 def _fake_quant_fixed(x: torch.Tensor, lb: float, ub: float, bits: int) -> torch.Tensor:
@@ -186,6 +216,10 @@ class Smoe:
             a0 = p0["A_diagonal"][:, :, 0, 0]
             p0["A_diagonal"] = np.ascontiguousarray(a0[..., None, None] * np.eye(d, dtype=np.float32))
         self.kernels = K
+        # kernel count of the engine: K itself when a kernel is instantiated for it, else the next instantiated count
+        pk = getattr(engine_factory, "padded_kernels", None) if engine_factory is not None else _default_padded_kernels
+        self._kp = K if pk is None else int(pk(d, C, K))
+        p0 = _pad_kernels(p0, self._kp)
         # use_diff_center (smoe.py:390-394,746-747): the trained variable is the OFFSET from the kernel
         # grid (initialised to zero); the engine works on grid + offset, the getters subtract the grid.
         self._mus_grid = None
@@ -217,7 +251,7 @@ class Smoe:
         self._params = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in p0.items()}
         self._best = {k: v.clone() for k, v in self._params.items()}      # smoe.py:861-866
         self._state = self._engine.new_adam_state(self._params)
-        self._active = torch.full((self.B,), (1 << K) - 1, dtype=torch.int32, device=dev)   # smoe.py:315
+        self._active = torch.full((self.B,), (1 << K) - 1, dtype=torch.int32, device=dev)   # smoe.py:315 (padding kernels unlisted)
         self._diverged = torch.zeros((self.B,), dtype=torch.int32, device=dev)
         self._loss0 = None
         self._best_loss_blocks = None
@@ -240,7 +274,7 @@ class Smoe:
     def _make_engine(self, pis_l1: float, u_l1: float):
         o1, o2, o3 = self.optimizer1, self.optimizer2, self.optimizer3
         cfg = EngineConfig(
-            block_shape=self.batch_size_valued, channels=self.image.shape[-1], kernels=self.kernels,
+            block_shape=self.batch_size_valued, channels=self.image.shape[-1], kernels=self._kp,
             precision=self.precision, margin=self.margin, use_determinant=bool(self.use_determinant),
             use_yuv=bool(self.use_yuv), train_pis=bool(self.train_pis), train_gammas=bool(self.train_gammas),
             train_musx=bool(self.train_musx),
@@ -312,8 +346,8 @@ class Smoe:
             assert self.rparams is not None, "quantize_params + rescaler first (smoe.py:1499-1501)"
             self.qvalid = False
             dev = eng.device
-            rp = {k: torch.from_numpy(np.ascontiguousarray(self.rparams[k][self.lo:self.hi], dtype=np.float32)).to(dev)
-                  for k in PARAM_NAMES}
+            rp = {k: np.ascontiguousarray(self.rparams[k][self.lo:self.hi], dtype=np.float32) for k in PARAM_NAMES}
+            rp = {k: torch.from_numpy(v).to(dev) for k, v in _pad_kernels(rp, self._kp).items()}
             out = eng.forward(self._target, rp, self._active, loss_w=self._loss_w,
                               want_recon=update_reconstruction, want_argmax=update_reconstruction,
                               want_gate=update_reconstruction, update_active=False)
@@ -348,7 +382,7 @@ class Smoe:
         am = am + (np.arange(self.lo, self.hi, dtype=np.int64) * self.kernels).reshape((-1,) + (1,) * d)
         am = sdist.allgather_blocks(am, self.num_blocks)
         argmax = blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
-        gate = out["gate_w"].cpu().numpy().reshape((self.B, self.kernels) + bs)
+        gate = out["gate_w"].cpu().numpy().reshape((self.B, self._kp) + bs)[:, :self.kernels]
         return image, argmax, sdist.allgather_blocks(gate, self.num_blocks)            # gate: (B,K,*bs)
 
     def _stitch(self, out, quantised=False):
@@ -479,6 +513,7 @@ class Smoe:
         out = {k: v.cpu().numpy().copy() for k, v in p.items()}
         if self._mus_grid is not None:                     # use_diff_center: report the trained offsets
             out["musX"] = out["musX"] - self._mus_grid
+        out = {k: np.ascontiguousarray(v[:, :self.kernels]) for k, v in out.items()}     # without the padding kernels
         if self.radial_as:                                 # the reference's variable is (K,) per model
             out["A_diagonal"] = np.ascontiguousarray(out["A_diagonal"][:, :, 0, 0])
         return {k: sdist.allgather_blocks(v, self.num_blocks) for k, v in out.items()}
@@ -560,7 +595,12 @@ class Smoe:
               "beta_pow": (float(self._state.c.beta1_power), float(self._state.c.beta2_power)),
               "step": int(self._state.c.step), "active": self._active.cpu().numpy(),
               "diverged": self._diverged.cpu().numpy(), "iter": self.iter, "losses": self.losses,
-              "mses": self.mses, "num_pis": self.num_pis, "shard": (self.lo, self.hi, self.num_blocks)}
+              "mses": self.mses, "num_pis": self.num_pis, "shard": (self.lo, self.hi, self.num_blocks),
+              # what train() needs to continue exactly where it stopped: the per-block best losses behind the best
+              # snapshot, the iteration-0 losses of the per-block stop rule (smoe.py:1565-1570) and the best scalars
+              "best_loss_blocks": None if self._best_loss_blocks is None else self._best_loss_blocks.cpu().numpy(),
+              "loss0": None if self._loss0 is None else self._loss0.cpu().numpy(),
+              "best_loss": self.best_loss, "best_mse": self.best_mse}
         with open(path if self.world_size == 1 else f"{path}.rank{self.rank}", "wb") as fd:
             pickle.dump(st, fd)
         return path
@@ -581,6 +621,9 @@ class Smoe:
         self._diverged.copy_(torch.from_numpy(st["diverged"]).to(dev))
         self.iter = st["iter"]
         self.losses, self.mses, self.num_pis = st["losses"], st["mses"], st["num_pis"]
+        self._best_loss_blocks = None if st.get("best_loss_blocks") is None else torch.from_numpy(st["best_loss_blocks"]).to(dev)
+        self._loss0 = None if st.get("loss0") is None else torch.from_numpy(st["loss0"]).to(dev)
+        self.best_loss, self.best_mse = st.get("best_loss"), st.get("best_mse", [])
         self.valid = False
 
 

@@ -41,9 +41,17 @@ def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6
     init_params = cp['params']
     if results_path is not None and not os.path.exists(results_path):
         os.mkdir(results_path)
+    # the graph the model was trained on (smoe_reconstruction.py:32-43 copies these from the pickle onto the model; here
+    # they go through the constructor so that the kernels are built for them).  Absent keys keep the defaults.
+    qmode = int(cp.get('quantization_mode') or 0)
     common = dict(init_params=init_params, bit_depths=list(bit_depths), precision=precision,
                   use_determinant=bool(cp.get('use_determinant', True)), use_yuv=bool(cp.get('use_yuv', False)),
-                  train_inverse_cov=bool(cp.get('train_inverse_cov', False)))    # absent key: trained by the CLI (False)
+                  train_inverse_cov=bool(cp.get('train_inverse_cov', False)),    # absent key: trained by the CLI (False)
+                  radial_as=bool(cp.get('radial_as', False)), quantization_mode=qmode,
+                  quantize_pis=bool(cp.get('quantized_pis', False)))
+    for key in ('lower_bounds', 'upper_bounds'):
+        if cp.get(key) is not None:
+            common[key] = list(cp[key])
     if np.asarray(init_params['pis']).ndim == 1:
         # ONE model for the whole image = the reference's own checkpoint layout (utils.save_model, kernels leading;
         # with reduce=True only the kernels with pis > 0) and this package's --mode shared pickles
@@ -53,9 +61,6 @@ def main(image_path, results_path, params_file, batches=1, bit_depths=(20, 18, 6
                           use_diff_center=False, engine_factory=_shared_engine_factory, **common)
     else:
         smoe = Smoe(orig, start_batches=batches, batch_size=list(cp['batch_size']), **common)
-    smoe.quantization_mode = cp.get('quantization_mode') or 0          # smoe_reconstruction.py:32-43
-    smoe.quantize_pis = bool(cp.get('quantized_pis'))
-    smoe.lower_bounds, smoe.upper_bounds = cp.get('lower_bounds'), cp.get('upper_bounds')
     with_q = bool(quant_params) and smoe.quantization_mode <= 0         # smoe_reconstruction.py:46-51
     if with_q:
         from .quantizer import quantize_params, rescaler

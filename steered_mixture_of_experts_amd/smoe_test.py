@@ -139,19 +139,10 @@ def main(args):
     if args.iterations != 0:
         smoe.train(args.iterations, val_iter=args.validation_iterations, ukl_iter=args.update_kernel_list_iterations,
                    pis_l1=args.l1reg)                                                 # smoe_test.py:119-121
-    if args.mode == 'blocks':
-        quant = args.quantization_mode != 0
-        save_model(smoe, args.results_path + "/params_best.pkl", best=True, quantize=quant)    # smoe_test.py:248-249
-        save_model(smoe, args.results_path + "/params_last.pkl", best=False, quantize=quant)
-    else:
-        import pickle
-        for name, params in (("params_best.pkl", smoe.get_best_params()), ("params_last.pkl", smoe.get_params())):
-            if smoe.rank == 0:
-                with open(os.path.join(args.results_path, name), 'wb') as fd:
-                    pickle.dump({'params': params, 'mses': smoe.get_mses(), 'losses': smoe.get_losses(),
-                                 'num_pis': smoe.get_num_pis(), 'use_yuv': smoe.use_yuv,
-                                 'use_determinant': smoe.use_determinant, 'batch_size': tuple(smoe.batch_size_valued),
-                                 'shape_of_img': tuple(smoe.image.shape), 'mode': 'shared'}, fd)
+    # both modes write the reference's checkpoint schema (utils.save_model; smoe_test.py:248-249)
+    quant = args.quantization_mode != 0
+    save_model(smoe, args.results_path + "/params_best.pkl", best=True, quantize=quant)
+    save_model(smoe, args.results_path + "/params_last.pkl", best=False, quantize=quant)
     rec = smoe.get_reconstruction()
     if smoe.rank == 0:
         write_image(rec, os.path.join(args.results_path, "reconstruction"), smoe.dim_domain, use_yuv, precision)

@@ -18,8 +18,12 @@ def save_model(smoe, path, best=False, reduce=False, quantize=False):
     ragged and is therefore off by default (the quantiser keeps a ``used_kernels`` mask
     instead); ``quantize`` stores ``smoe.qparams`` with the reference's metadata keys."""
     params = smoe.get_best_params() if best else smoe.get_params()
-    if reduce:
+    shared = np.asarray(params['pis']).ndim == 1                      # ONE model for the image (SharedSmoe)
+    if reduce and not shared:
         raise NotImplementedError("reduce=True would drop the block structure of per-block parameters")
+    if reduce:                                                       # utils.py:21-28: keep the kernels with pis > 0
+        keep = np.asarray(params['pis']) > 0
+        params = {k: np.asarray(v)[keep] for k, v in params.items()}
     cp = {'params': params, 'mses': smoe.get_mses(), 'losses': smoe.get_losses(), 'num_pis': smoe.get_num_pis(),
           'quantization_mode': smoe.quantization_mode, 'quantized_pis': smoe.quantize_pis,
           'lower_bounds': smoe.lower_bounds, 'upper_bounds': smoe.upper_bounds,
@@ -28,8 +32,10 @@ def save_model(smoe, path, best=False, reduce=False, quantize=False):
           # additions needed to rebuild the block tiling and the form of the kernels (the reference's Smoe defaults to
           # train_inverse_cov=True while its CLI trains with False, smoe.py:41 / smoe_test.py:342)
           'train_inverse_cov': bool(getattr(smoe, 'train_inverse_cov', False)),
-          'batch_size': tuple(smoe.batch_size_valued), 'shape_of_img': tuple(smoe.image.shape)}
-    if quantize:                                                     # utils.py:37-56
+          'radial_as': bool(getattr(smoe, 'radial_as', False)), 'bit_depths': list(smoe.bit_depths),
+          'batch_size': tuple(smoe.batch_size_valued), 'shape_of_img': tuple(smoe.image.shape),
+          'mode': 'shared' if shared else 'blocks'}
+    if quantize and smoe.qparams is not None:                        # utils.py:37-56
         qparams = dict(smoe.qparams)
         qparams.update({'dim_of_domain': smoe.dim_domain, 'dim_of_output': smoe.image.shape[-1],
                         'shape_of_img': smoe.image.shape[:-1], 'used_ranges': False,

@@ -595,3 +595,88 @@ def test_shared_facade_with_a_loss_mask():
         assert np.allclose(got[k], pn[k][0], rtol=1e-4, atol=1e-3 if k.startswith("A_") else 1e-5), k
     assert np.allclose([v for _, v in s.get_losses()], info["hist"]["loss"], rtol=1e-5)
     assert info["hist"]["loss"][0] < 0.8 * plain["hist"]["loss"][0]            # the mask really weighs the loss
+
+
+def test_resume_equals_uninterrupted_training(tmp_path):
+    """train(2n) == train(n) + checkpoint / restore into a fresh model + train(n), including the best snapshot and the
+    per-block stop rule's iteration-0 losses (restore() lost _best_loss_blocks and _loss0)."""
+    img = _image(32, 48, seed=21)
+
+    def fresh():
+        s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True,
+                 engine_factory=OracleEngine)
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1.0))
+        return s
+    a = fresh()
+    a.train(8, val_iter=2)
+    b = fresh()
+    b.train(4, val_iter=2)
+    path = b.checkpoint(str(tmp_path / "ck.pkl"))
+    c = fresh()
+    c.restore(path)
+    assert c._best_loss_blocks is not None and c._loss0 is not None and c.best_loss == b.best_loss
+    assert np.array_equal(c._loss0.numpy(), b._loss0.numpy())
+    c.train(4, val_iter=2)
+    pa, pc = a.get_params(), c.get_params()
+    ba, bc = a.get_best_params(), c.get_best_params()
+    for k in pa:
+        assert np.array_equal(pa[k], pc[k]), k
+        assert np.array_equal(ba[k], bc[k]), k
+    assert c.get_iter() == a.get_iter() == 8
+
+
+def test_unsupported_kernel_counts_are_padded_with_prior_zero_kernels():
+    """A kernel count without its own instantiation runs on the next instantiated count; the padding kernels have prior
+    0, so `bool_mask = kernel_list & pis > 0` (smoe.py:480,738) drops them: results equal the unpadded model's."""
+    img = _image(32, 32, seed=5)
+
+    class Padded:
+        """engine factory that, like libsmoe_hip.so, only has even kernel counts"""
+        def __call__(self, cfg, device):
+            assert cfg.kernels % 2 == 0
+            return OracleEngine(cfg, device)
+
+        @staticmethod
+        def padded_kernels(d, C, K):
+            return K + (K % 2)
+    kw = dict(train_inverse_cov=False, kernels_per_dim=[1, 3], batch_size=[16, 16], use_determinant=True, quantize_pis=True)
+    ref = Smoe(img, engine_factory=OracleEngine, **kw)
+    pad = Smoe(img, engine_factory=Padded(), **kw)
+    assert ref._kp == 3 and pad._kp == 4 and pad.kernels == 3
+    for s in (ref, pad):
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+        s.train(6, val_iter=3, pis_l1=0.1)
+    pr, pp = ref.get_params(), pad.get_params()
+    for k in pr:
+        assert pp[k].shape == pr[k].shape and np.allclose(pp[k], pr[k], rtol=1e-6, atol=1e-7), k
+    assert np.array_equal(ref.get_reconstruction(), pad.get_reconstruction())
+    assert np.array_equal(ref.get_weight_matrix_argmax(), pad.get_weight_matrix_argmax())
+    assert ref.get_weight_matrix().shape == pad.get_weight_matrix().shape
+    assert ref.get_num_pis() == pad.get_num_pis() and np.allclose(ref.get_losses(), pad.get_losses(), rtol=1e-6)
+    assert len(pad.kernel_list_per_batch[0]) == 3
+
+
+def test_shared_mode_cli_checkpoint_decodes(tmp_path):
+    """CLI --mode shared -> smoe_reconstruction (the shared-mode writer dropped the bounds, quantize_pis and
+    train_inverse_cov; decoding crashed on the missing bounds and would have rebuilt another graph)."""
+    import steered_mixture_of_experts_amd.smoe as smod
+    import steered_mixture_of_experts_amd.smoe_reconstruction as rec
+    import steered_mixture_of_experts_amd.smoe_test as cli
+    from fake_engine import OracleSharedEngine
+    img = _image(32, 48, seed=9)
+    np.save(tmp_path / "img.npy", np.uint8(np.round(img * 255)))
+    f1, f2, f3 = smod._default_engine_factory, smod._default_shared_factory, rec._shared_engine_factory
+    smod._default_engine_factory = lambda cfg, device: OracleEngine(cfg, device)
+    smod._default_shared_factory = lambda cfg, device: OracleSharedEngine(cfg, device)
+    rec._shared_engine_factory = OracleSharedEngine
+    try:
+        out = str(tmp_path / "res")
+        g = cli.main(cli.build_parser().parse_args(["-i", str(tmp_path / "img.npy"), "-r", out, "-k", "3", "-bz", "16", "16",
+                                                    "-n", "2", "-v", "2", "--mode", "shared", "-tiv", "true"]))
+        cp = utils.load_checkpoint(out + "/params_last.pkl")
+        assert cp["mode"] == "shared" and cp["train_inverse_cov"] is True and cp["quantized_pis"] is True
+        assert cp["lower_bounds"] is not None and cp["upper_bounds"] is not None and cp["params"]["pis"].shape == (9,)
+        recon, loss, mse = rec.main(str(tmp_path / "img.npy"), str(tmp_path / "dec"), out + "/params_last.pkl")
+        assert np.array_equal(recon, g.get_reconstruction())          # the same graph: inverse-covariance form, quantised pis
+    finally:
+        smod._default_engine_factory, smod._default_shared_factory, rec._shared_engine_factory = f1, f2, f3
