@@ -18,7 +18,7 @@ def main():
     K, N = 4, 256
     blocks = blk.synthetic_blocks(B, shape, C, 7)
     p0 = blk.init_block_params(blocks, kpd)
-    for tiling in (16, 64):
+    for tiling in (16, 32, 64):
         eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, use_yuv=(C == 3), quantize_pis=True))
         eng.set_tiling(tiling)
         T = torch.from_numpy(blk.to_planar(blocks)).cuda()

@@ -1,0 +1,10 @@
+#!/bin/bash
+# kernel trace of the evaluation pass: scripts/prof_forward.sh <outdir>
+OUT=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$OUT"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fwd" -- python3 scripts/forward_timing.py > "$OUT/fwd.log" 2>&1
+echo rc=$?
+f=$(ls $OUT/fwd/*/*kernel_stats.csv | head -1)
+cp "$f" "$OUT/forward_kernel_stats.csv"
+head -12 "$OUT/forward_kernel_stats.csv"

@@ -599,6 +599,22 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
 // ---------------------------------------------------------------------------
 // LDS carve-up shared by the fit and forward kernels
 // ---------------------------------------------------------------------------
+// The parameter tensors (get_params layout, leading block axis) of the workgroup's NB consecutive blocks are six
+// contiguous runs: they move between global memory and an LDS tile with coalesced accesses, and the slot owners pick /
+// deposit their packed slots in the tile (decode_slot with the block index inside the workgroup).
+template <int D, int C, int K>
+struct ParamTile {
+    __host__ __device__ static constexpr int elems(int t) {            // floats per kernel of tensor t
+        return (t == 0) ? 1 : ((t == 1) ? D : ((t == 2 || t == 3) ? D * D : ((t == 4) ? D * C : C)));
+    }
+    __host__ __device__ static constexpr int before(int t) {           // floats per kernel in front of tensor t
+        int n = 0;
+        for (int u = 0; u < t; ++u) n += elems(u);
+        return n;
+    }
+    static constexpr int PER_KERNEL = before(6);                       // 1 + D + 2 D^2 + D C + C
+};
+
 template <int D, int C, int K, int G, int WAVES>
 struct Tile {
     using Lt = Layout<D, C, K>;
@@ -625,6 +641,7 @@ struct Tile {
         return (G == 64) ? ((2 * s + (sub & 1)) * RPR + (sub >> 1)) : (sub + s * G);
     }
     static constexpr int THREADS = WAVES * 64;
+    static_assert(NB * K * ParamTile<D, C, K>::PER_KERNEL <= WAVES * CH * ROW, "the parameter tile of a workgroup is staged in the reduction scratch");
     static constexpr int MV_STRIDE = round_up(2 * Lt::NPAR, 4);   // Adam m,v image of one block
     // Distance between the blocks of a wavefront in the target / loss-weight planes.  With 16 lanes per block the two
     // blocks of a 32-lane group read the same LDS banks (block size = multiple of 32 floats: SQ_LDS_BANK_CONFLICT = 18 % of
@@ -666,30 +683,88 @@ struct Tile {
     }
 };
 
+// Coordinates, targets and loss weights of the workgroup's blocks -> LDS.  The NB blocks are consecutive in the
+// [B, C, N] / [B, N] arrays, so each plane set is ONE contiguous run of floats: 16-byte global loads and LDS stores
+// when the block size is a multiple of four pixels (blocks past the end of the batch re-read the last block).
 template <int D, int C, int K, int G, int WAVES, int CR = D>
 __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, const float* __restrict__ target,
                                              const float* __restrict__ loss_w, int B, int N, int blk0,
                                              float* __restrict__ lds) {
     using T = Tile<D, C, K, G, WAVES>;
+    static_assert(T::TGT_PAD == 0, "the staged planes of a workgroup are one contiguous run");
     float* s_coords = lds + T::off_coords();
     float* s_tgt = lds + T::off_tgt(N, CR);
     float* s_lw = lds + T::off_lw(N, CR);
+    auto copy_planes = [&](const float* __restrict__ src, float* __restrict__ dst, int per) {
+        // per = floats per block (multiple of 4 on the vector path)
+        if ((per & 3) == 0) {
+            const int per4 = per >> 2;
+            for (int i = threadIdx.x; i < T::NB * per4; i += T::THREADS) {
+                const int lb = i / per4;
+                const int rem = i - lb * per4;
+                const int b = min(blk0 + lb, B - 1);
+                reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src + (size_t)b * per)[rem];
+            }
+        } else {
+            for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) {
+                const int lb = i / per;
+                const int rem = i - lb * per;
+                const int b = min(blk0 + lb, B - 1);
+                dst[i] = src[(size_t)b * per + rem];
+            }
+        }
+    };
     for (int i = threadIdx.x; i < CR * N; i += T::THREADS) s_coords[i] = coords[i];
-    const int per = C * N;
-    for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) {
-        const int lb = i / per;
-        const int rem = i - lb * per;
-        const int b = min(blk0 + lb, B - 1);
-        s_tgt[lb * T::tgt_stride(N) + rem] = target[(size_t)b * per + rem];
+    copy_planes(target, s_tgt, C * N);
+    if (loss_w != nullptr) copy_planes(loss_w, s_lw, N);
+}
+
+// The tile is the concatenation of the six runs; element i of it belongs to tensor t(i).  Fetch = global -> registers
+// (all loads of a thread go out together: ONE memory latency for parameters AND Adam slots), put = registers -> LDS.
+template <int D, int C, int K, int NB, int THREADS>
+struct TileIO {
+    using PT = ParamTile<D, C, K>;
+    static constexpr int TOTAL = NB * K * PT::PER_KERNEL;
+    static constexpr int MAXE = (TOTAL + THREADS - 1) / THREADS;
+    // tensor of tile element i and its index inside that tensor's run
+    __device__ static __forceinline__ void locate(int i, int& t, int& local) {
+        t = 0; local = i;
+#pragma unroll
+        for (int u = 1; u < 6; ++u)
+            if (i >= NB * K * PT::before(u)) { t = u; local = i - NB * K * PT::before(u); }
     }
-    if (loss_w != nullptr) {
-        for (int i = threadIdx.x; i < T::NB * N; i += T::THREADS) {
-            const int lb = i / N;
-            const int rem = i - lb * N;
-            const int b = min(blk0 + lb, B - 1);
-            s_lw[lb * T::lw_stride(N) + rem] = loss_w[(size_t)b * N + rem];
+    __device__ static __forceinline__ void fetch(const smoe_params& s, int blk0, int B, float (&v)[MAXE]) {
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            const int i = threadIdx.x + e * THREADS;
+            v[e] = 0.0f;
+            if (i < TOTAL) {
+                int t, local;
+                locate(i, t, local);
+                const int el = PT::elems(t);
+                const long g = min((long)blk0 * K * el + local, (long)B * K * el - 1);     // blocks past the batch: valid memory
+                v[e] = pick(s, t)[g];
+            }
         }
     }
+    __device__ static __forceinline__ void put(const float (&v)[MAXE], float* __restrict__ tile) {
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) {
+            const int i = threadIdx.x + e * THREADS;
+            if (i < TOTAL) tile[i] = v[e];
+        }
+    }
+};
+
+// index of packed slot j of workgroup-local block lb inside the tile
+template <int D, int C, int K, int NB>
+__device__ __forceinline__ int tile_index(int j, int lb) {
+    int tensor, kern; long off;
+    decode_slot<D, C, K>(j, lb, tensor, off, kern);
+    using PT = ParamTile<D, C, K>;
+    const int before = (tensor == 0) ? PT::before(0) : ((tensor == 1) ? PT::before(1) : ((tensor == 2) ? PT::before(2)
+                     : ((tensor == 3) ? PT::before(3) : ((tensor == 4) ? PT::before(4) : PT::before(5)))));
+    return NB * K * before + (int)off;
 }
 
 // Cross-lane reduction of acc[FIRST..NSLOT) over the G lanes of a block through an LDS transpose: the lane that owns
@@ -1041,6 +1116,9 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         if (j < Lt::NPAR) {
             int tensor, kern; long off;
             decode_slot<D, C, K>(j, b, tensor, off, kern);
+            // (the coalesced tile path of the evaluation kernel -- TileIO -- was measured here too: three LDS hand-offs for
+            // parameters, m and v cost more than these scattered loads of lines the 16 blocks share: -2 % at 20 iterations
+            // per launch, -0.9 % at 100)
             s_par[j] = pick(a.p, tensor)[off];
             s_mv[2 * j] = pick(a.m, tensor)[off];
             s_mv[2 * j + 1] = pick(a.v, tensor)[off];
@@ -1418,7 +1496,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 // ---------------------------------------------------------------------------
 // forward (evaluation) kernel
 // ---------------------------------------------------------------------------
-template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false, bool IC = false>
+// HL: hoisting level as in fit_kernel (the launcher passes the same rule); the SSIM kernels run with HL = 0.
+template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false, bool IC = false, int HL = 0>
 __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -1435,15 +1514,19 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     const bool valid_b = b_raw < B;
     const int b = valid_b ? b_raw : B - 1;
 
+    constexpr int CR = D - HL;                     // only the coordinates read per pixel are staged
     float* s_coords = lds + T::off_coords();
-    float* s_par = lds + T::off_par(N, D) + lb * Lt::LP_STRIDE;
-    float* s_scratch = lds + T::off_scratch(N, D) + wave * (T::CH * T::ROW);
-    const float* s_tgt = lds + T::off_tgt(N, D) + lb * T::tgt_stride(N);
-    const float* s_lw = lds + T::off_lw(N, D) + lb * T::lw_stride(N);
+    float* s_par = lds + T::off_par(N, CR) + lb * Lt::LP_STRIDE;
+    float* s_scratch = lds + T::off_scratch(N, CR) + wave * (T::CH * T::ROW);
+    const float* s_tgt = lds + T::off_tgt(N, CR) + lb * T::tgt_stride(N);
+    const float* s_lw = lds + T::off_lw(N, CR) + lb * T::lw_stride(N);
     const bool has_lw = a.loss_w != nullptr;
 
-    stage_inputs<D, C, K, G, WAVES>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
-    float* s_ssim = lds + T::off_ssim(N, has_lw, D);
+    using IO = TileIO<D, C, K, T::NB, T::THREADS>;
+    float vp[IO::MAXE];
+    IO::fetch(a.p, blk0, B, vp);                   // in flight together with the staging loads
+    stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
     const int bh = a.bh, bw = a.bw;
     const float* s_Tr = s_ssim;
     const float* s_Tc = s_ssim + bh * 11;
@@ -1461,18 +1544,22 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
         }
     }
+    // parameters: one coalesced tile load through the reduction scratch, the owners pick their packed slots
+    {
+        float* s_tile = lds + T::off_scratch(N, CR);
+        IO::put(vp, s_tile);
+        __syncthreads();
 #pragma unroll
-    for (int s = 0; s < T::SPL; ++s) {
-        const int j = T::slot_of(sub, s);
-        if (j < Lt::NPAR) {
-            int tensor, kern; long off;
-            decode_slot<D, C, K>(j, b, tensor, off, kern);
-            s_par[j] = pick(a.p, tensor)[off];
-        } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
-            const int k = j - Lt::S_CNT;
-            s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
-        } else if (j == Lt::S_LOSS) {
-            s_par[Lt::LP_FROZEN] = 0.0f;
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = T::slot_of(sub, s);
+            if (j < Lt::NPAR) {
+                s_par[j] = s_tile[tile_index<D, C, K, T::NB>(j, lb)];
+            } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
+                const int k = j - Lt::S_CNT;
+                s_par[Lt::LP_ACT + k] = ((a.active[b] >> k) & 1u) ? 1.0f : 0.0f;
+            } else if (j == Lt::S_LOSS) {
+                s_par[Lt::LP_FROZEN] = 0.0f;
+            }
         }
     }
     __syncthreads();
@@ -1481,51 +1568,60 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     R.load(s_par);
     if (a.kc.qmode != 0 || a.kc.qpis != 0) quantize_packed<D, C, K, QUANT>(R.P, a.kc);
     R.template derive<IC>(a.kc);
+    float xc[D];                                   // coordinates of the lane's first pixel (hoisted axes: of all its pixels)
+#pragma unroll
+    for (int l = 0; l < D; ++l) xc[l] = a.coords[l * N + min(sub, N - 1)];
+    if (HL > 0) hoist_const<D, C, K, HL, IC>(R, xc);
 
     float acc[Lt::NSLOT];
 #pragma unroll
     for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
 
     const int pxl = (N + G - 1) / G;
-    for (int i = 0; i < pxl; ++i) {
-        const int n = i * G + sub;
-        if (n < N) {
-            float x[D], t[C];
+    const int full = N / G;                        // steps in which every lane of the block has a pixel
+    unsigned long long flags[K];                   // influence votes of the full steps (scalar unit), see pixel<>
 #pragma unroll
-            for (int l = 0; l < D; ++l) x[l] = s_coords[l * N + n];
+    for (int k = 0; k < K; ++k) flags[k] = 0ull;
+    auto step = [&](int n, auto voted) {
+        float x[D], t[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
-            const float lw = has_lw ? s_lw[n] : 1.0f;
-            PixelOut<D, C, K> o;
-            pixel<D, C, K, false, 0, false, IC>(R, a.kc, x, t, lw, acc, o);
-            if (SSIM) {
+        for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+        const float lw = has_lw ? s_lw[n] : 1.0f;
+        PixelOut<D, C, K> o;
+        pixel<D, C, K, false, HL, false, IC, decltype(voted)::value>(R, a.kc, x, t, lw, acc, o, nullptr, flags);
+        if (SSIM) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
+        }
+        if (valid_b) {
+            if (a.recon != nullptr) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) a.recon[((size_t)b * C + c) * N + n] = o.q[c];
             }
-            if (valid_b) {
-                if (a.recon != nullptr) {
+            if (a.gate_w != nullptr) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) a.recon[((size_t)b * C + c) * N + n] = o.q[c];
-                }
-                if (a.gate_w != nullptr) {
+                for (int k = 0; k < K; ++k) a.gate_w[((size_t)b * K + k) * N + n] = o.wt[k];
+            }
+            if (a.argmax != nullptr) {
+                // tf.argmax over the kernels with influence (smoe.py:833): first maximum;
+                // a pixel with no influential kernel resolves to the first listed kernel
+                // of the block, which is only known after the block reduction -> 255 for now.
+                float best = 0.0f;
+                int arg = 255;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) a.gate_w[((size_t)b * K + k) * N + n] = o.wt[k];
+                for (int k = 0; k < K; ++k) {
+                    if (o.wt[k] > best) { best = o.wt[k]; arg = k; }
                 }
-                if (a.argmax != nullptr) {
-                    // tf.argmax over the kernels with influence (smoe.py:833): first maximum;
-                    // a pixel with no influential kernel resolves to the first listed kernel
-                    // of the block, which is only known after the block reduction -> 255 for now.
-                    float best = 0.0f;
-                    int arg = 255;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if (o.wt[k] > best) { best = o.wt[k]; arg = k; }
-                    }
-                    a.argmax[(size_t)b * N + n] = (uint8_t)arg;
-                }
+                a.argmax[(size_t)b * N + n] = (uint8_t)arg;
             }
         }
-    }
+    };
+    for (int i = 0; i < full; ++i) step(i * G + sub, std::true_type{});
+    if (full < pxl && full * G + sub < N) step(full * G + sub, std::false_type{});
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[Lt::S_CNT + k] += ((flags[k] >> lane) & 1ull) ? 1.0f : 0.0f;
 
     if constexpr (SSIM) {                              // loss_pixel = 1 - SSIM (smoe.py:1006-1010)
         wave_lds_sync();
@@ -1664,8 +1760,11 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
     auto kern = forward_kernel<D, C, K, G, WAVES>;
+    int hl = 0;
+    if (a.hoist >= 1) { kern = forward_kernel<D, C, K, G, WAVES, false, false, false, 1>; hl = 1; }
+    if (D == 3 && a.hoist >= 2) { kern = forward_kernel<D, C, K, G, WAVES, false, false, false, (D == 3 ? 2 : 1)>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1696,8 +1795,11 @@ hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
-    auto kern = a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, false, true, true> : forward_kernel<D, C, K, G, WAVES, false, true>;
+    const bool ic = a.kc.inverse_cov != 0;
+    auto kern = ic ? forward_kernel<D, C, K, G, WAVES, false, true, true> : forward_kernel<D, C, K, G, WAVES, false, true>;
+    int hl = 0;
+    if (a.hoist >= 1) { kern = ic ? forward_kernel<D, C, K, G, WAVES, false, true, true, 1> : forward_kernel<D, C, K, G, WAVES, false, true, false, 1>; hl = 1; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
@@ -1725,8 +1827,11 @@ hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd_ic(const FwdArgs& a, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr);
     auto kern = forward_kernel<D, C, K, G, WAVES, false, false, true>;
+    int hl = 0;
+    if (a.hoist >= 1) { kern = forward_kernel<D, C, K, G, WAVES, false, false, true, 1>; hl = 1; }
+    if (D == 3 && a.hoist >= 2) { kern = forward_kernel<D, C, K, G, WAVES, false, false, true, (D == 3 ? 2 : 1)>; hl = 2; }
+    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;

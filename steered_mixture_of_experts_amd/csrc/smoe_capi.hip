@@ -114,6 +114,16 @@ int check_quant_config(int mode, int quantize_pis, const int32_t* bits, const fl
     return SMOE_OK;
 }
 
+// Lanes walk the block with stride G: when G is a multiple of the last axis (of the last two axes), a lane's last (two)
+// coordinate(s) never change and the kernels hoist every term in them out of the pixel loop (fit_kernel<..., HL>).
+int hoist_level(const smoe_context* h, const smoe::Variant* v) {
+    const smoe_config& c = h->cfg;
+    const int last = c.block_shape[c.dim - 1];
+    if (v->G % last != 0) return 0;
+    if (c.dim == 3 && v->G % (last * c.block_shape[c.dim - 2]) == 0) return 2;
+    return 1;
+}
+
 // What a launch needs from a variant (the basic instantiations of smoe_variants.def lack the SSIM / mode-2,3 kernels).
 bool variant_serves(const smoe::Variant& v, const smoe_context* h) {
     if (h->cfg.ssim_opt) return v.fit_ssim != nullptr;
@@ -382,6 +392,7 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.target = target; a.loss_w = loss_w; a.p = *p;
     a.recon = recon; a.argmax = argmax; a.gate_w = gate_w; a.loss = loss; a.sse = sse; a.active = active;
     a.coords = h->d_coords; a.B = num_blocks; a.N = h->N; a.update_active = update_active;
+    a.hoist = hoist_level(h, v);
     a.reg_pi = h->cfg.pis_l1 / (float)(h->cfg.start_pis > 0 ? h->cfg.start_pis : h->cfg.kernels);
     a.reg_u = h->cfg.u_l1;
     a.kc = h->kc;
@@ -417,15 +428,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
     a.reg_u = c.u_l1;
     a.kc = h->kc;
-    // lanes walk the block with stride G: when G is a multiple of the last axis (of the last two
-    // axes), a lane's last (two) coordinate(s) never change and the kernel hoists them
-    // (fit_kernel<..., HL>)
-    int hoist = 0;
-    const int last = c.block_shape[c.dim - 1];
-    if (v->G % last == 0) {
-        hoist = 1;
-        if (c.dim == 3 && v->G % (last * c.block_shape[c.dim - 2]) == 0) hoist = 2;
-    }
+    const int hoist = hoist_level(h, v);
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1];
     if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");

@@ -71,6 +71,7 @@ struct FwdArgs {
     uint32_t* active;         // [B]
     const float* coords;
     int B, N, update_active;
+    int hoist;                // trailing axes whose coordinate is a lane constant (same rule as smoe_fit)
     float reg_pi, reg_u;
     const float* ssim_T;
     int bh, bw;

@@ -26,6 +26,28 @@ SHAPES = [
     ((7, 5), 1, [2, 2], False),
     ((12, 10, 3), 3, [2, 2, 1], True),
 ]
+# kernel grids / channel counts outside the BASELINE shapes (csrc/smoe_variants.def, basic instantiations):
+# the reference takes any grid (smoe.py:2146-2163)
+EXTRA_SHAPES = [
+    ((16, 16), 1, [3, 3], False),
+    ((16, 16), 3, [3, 3], True),
+    ((16, 16), 1, [1, 1], False),
+    ((16, 16), 3, [1, 2], True),
+    ((16, 16), 3, [3, 1], False),
+    ((16, 16), 1, [2, 3], False),
+    ((16, 16), 1, [3, 4], False),
+    ((16, 16), 1, [4, 4], False),
+    ((16, 16), 3, [2, 3], True),
+    ((8, 8, 4), 1, [2, 2, 1], False),        # grayscale video
+    ((8, 8, 8), 1, [2, 2, 2], False),
+    ((8, 8, 4), 1, [1, 3, 1], False),
+    ((12, 12, 4), 3, [1, 3, 2], True),
+    ((8, 8, 8), 3, [2, 2, 2], True),
+    ((16, 16, 4), 3, [1, 1, 1], True),
+]
+ALL_SHAPES = [(s, 16) for s in SHAPES] + [(s, 64) for s in SHAPES] + [(s, 32) for s in SHAPES[:5]] \
+    + [(s, 16) for s in EXTRA_SHAPES] + [(s, 64) for s in EXTRA_SHAPES]
+ALL_IDS = ["x".join(map(str, s[0])) + f"-c{s[1]}-k" + "x".join(map(str, s[2])) + f"-g{t}" for s, t in ALL_SHAPES]
 
 
 def _engine(shape, C, K, **kw):
@@ -88,15 +110,15 @@ def test_coords_match_numpy_linspace():
         eng.close()
 
 
-@pytest.mark.parametrize("shape,C,kpd,yuv", SHAPES)
-@pytest.mark.parametrize("tiling", [16, 64])
-def test_forward_parity(shape, C, kpd, yuv, tiling):
+@pytest.mark.parametrize("case,tiling", ALL_SHAPES, ids=ALL_IDS)
+def test_forward_parity(case, tiling):
+    shape, C, kpd, yuv = case
     B = 37      # ragged: not a multiple of the blocks per workgroup
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 100 + len(shape) + C, pis_l1=0.2, u_l1=0.003)
     rng = np.random.default_rng(5)
     active = rng.uniform(size=(B, K)) < 0.85
     p["pis"][3, 0] = 0.0            # pis <= 0 kernels are absent (smoe.py:480)
-    p["pis"][4, 1] = -0.1
+    p["pis"][4, K - 1] = -0.1
     lw = rng.uniform(0.0, 1.0, size=(B, tgt.shape[1])).astype(np.float32)
     ref = o.forward(p, tgt, coords, active, cfg, lw, np.float32)
     ref64 = o.forward(p, tgt, coords, active, cfg, lw, np.float64)
@@ -135,17 +157,17 @@ def test_forward_parity(shape, C, kpd, yuv, tiling):
     assert (new_act == ref["active_new"])[~unstable].all()
     am = out["argmax"].cpu().numpy().astype(np.int64)
     # ties between two kernels' gate values within rounding are allowed to differ
-    srt = np.sort(ref64["wt"], axis=1)
+    srt = np.sort(np.concatenate([ref64["wt"], np.zeros_like(ref64["wt"][:, :1])], axis=1), axis=1)   # (K = 1: vs zero)
     close_top = (srt[:, -1, :] - srt[:, -2, :]) < 1e-6
     assert (am == ref["argmax"])[~close_top & ~unstable.any(axis=1)[:, None]].all()
     eng.close()
 
 
-@pytest.mark.parametrize("shape,C,kpd,yuv", SHAPES)
-@pytest.mark.parametrize("tiling", [16, 64])
-def test_one_step_parity(shape, C, kpd, yuv, tiling):
+@pytest.mark.parametrize("case,tiling", ALL_SHAPES, ids=ALL_IDS)
+def test_one_step_parity(case, tiling):
     """One train iteration: gradients enter Adam's first step as sign-like updates, so
     parity is checked on m (= 0.1*g, exposes the gradient itself), v and the parameters."""
+    shape, C, kpd, yuv = case
     B = 21
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 300 + len(shape) + C)
     active = np.ones((B, K), dtype=bool)
@@ -182,10 +204,14 @@ def test_one_step_parity(shape, C, kpd, yuv, tiling):
     got = _to_host(dp)
     for name in o.PARAM_NAMES:
         g_ref = ref["grads"][name][clean]
-        scale = np.abs(ref64["grads"][name][clean]).max() + 1e-30
+        # (one kernel per block: w = 1, the gradients of pis / musX / A vanish identically and only rounding residue of the
+        # hardware reciprocal is left -- measured against the scale of the expert gradients then)
+        scale = max(np.abs(ref64["grads"][name][clean]).max(), (1.0 if K == 1 else 0.0) * np.abs(ref64["grads"]["nu_e"][clean]).max()) + 1e-30
         g_got = m[name][clean] / 0.1
         err = np.abs(g_got - g_ref).max() / scale
         assert err < 2e-5, (name, err)
+        if K == 1 and name in ("pis", "musX", "A_diagonal", "A_corr"):
+            continue        # identically zero gradients: Adam turns the rounding residue (< 2e-5 of the expert scale) into a step
         perr = np.abs(got[name][clean] - p_ref[name][clean])
         # first TF1-Adam step: delta = lr*g/(|g| + eps*sqrt(1-b1)... ) = lr*g/(|g| + 3.16e-7):
         # an element's sensitivity to gradient noise dg is lr*e/(|g|+e)^2 with e = 1e-8/sqrt(1e-3)
