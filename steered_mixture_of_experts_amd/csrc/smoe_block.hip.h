@@ -60,7 +60,9 @@ struct Layout {
     static constexpr int LP_ACT = NPAR;
     static constexpr int LP_FROZEN = NPAR + K;
     static constexpr int LP_QPI = NPAR + K + 1;
-    static constexpr int LP_STRIDE = round_up(NPAR + 2 * K + 1, 4);
+    static constexpr int LP_ZERO = NPAR + 2 * K + 1;    // constant cells 0.0f / 1.0f: operands of the unused terms of a
+    static constexpr int LP_ONE = NPAR + 2 * K + 2;     // slot's gradient descriptor (owner_gradient)
+    static constexpr int LP_STRIDE = round_up(NPAR + 2 * K + 3, 4);
 };
 
 // Where packed parameter j of block b lives in the reference's tensors
@@ -596,6 +598,80 @@ __device__ __forceinline__ void finish_partials(const BlockRegs<D, C, K>& R, con
     }
 }
 
+// Owner-side post-transform (tilings with G >= 32).  After the reduction the owner of slot j holds the raw total; its
+// gradient is linear in a few raw totals of the same kernel with coefficients that are parameters of that kernel:
+//   g = c_self * tot + P1*T1 + P2*T2 + P3*T3 + (act ? 1/PR : 0) * TR
+// (the same maps as finish_partials: d/dpi = su/pi; d/dmu_l = sum_m A[l][m] suz_m; d/dA_lm = mu_l suz_m - sxz_lm
+// [+ su/A_ll on the diagonal with use_determinant]; IC: d/dmu_l = sum_m A_lm sur_m, d/dA_ll = -surr_ll/2 [+ su/A_ll],
+// d/dA_corr = -surr_lm; nu_e / gamma_e: the raw sums).  The MU slots are published scaled by 1/SQ (suz = suz'/SQ).
+// A descriptor holds the LDS byte addresses of the operands; unused terms point at the constant cells LP_ZERO / LP_ONE.
+struct SlotDesc {
+    float c_self, pub_scale;
+    uint32_t T1, T2, T3, TR, P1, P2, P3, PR, FLAG, PIV;
+};
+
+template <int D, int C, int K, bool IC>
+__device__ __forceinline__ SlotDesc build_slot_desc(int j, uint32_t tot_base, uint32_t img_base, uint32_t par_base,
+                                                    bool patch_pis, bool use_det) {
+    using Lt = Layout<D, C, K>;
+    const uint32_t ZERO = par_base + 4u * Lt::LP_ZERO, ONE = par_base + 4u * Lt::LP_ONE;
+    const int k = j / Lt::PK, o = j - k * Lt::PK;
+    const uint32_t Tk = tot_base + 4u * (uint32_t)(k * Lt::PK), Pk = img_base + 4u * (uint32_t)(k * Lt::PK);
+    SlotDesc d;
+    d.c_self = 1.0f; d.pub_scale = 1.0f;
+    d.T1 = d.T2 = d.T3 = d.TR = ZERO;
+    d.P1 = d.P2 = d.P3 = ZERO;
+    d.PR = ONE;
+    d.FLAG = img_base + 4u * (uint32_t)(Lt::LP_ACT + k);
+    d.PIV = patch_pis ? par_base + 4u * (uint32_t)(Lt::LP_QPI + k) : Pk + 4u * Lt::O_PI;
+    if (o == Lt::O_PI) {
+        d.c_self = 0.0f; d.TR = Tk + 4u * Lt::O_PI; d.PR = d.PIV;
+    } else if (o < Lt::O_A) {
+        const int l = o - Lt::O_MU;
+        d.c_self = 0.0f;
+        d.pub_scale = IC ? 1.0f : SMOE_INV_SQ;
+        int n = 0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            if (IC || m <= l) {
+                const int hi = (l > m) ? l : m, lo = (l > m) ? m : l;
+                const uint32_t P = Pk + 4u * (uint32_t)(Lt::O_A + hi * (hi + 1) / 2 + lo), T = Tk + 4u * (uint32_t)(Lt::O_MU + m);
+                if (n == 0) { d.P1 = P; d.T1 = T; } else if (n == 1) { d.P2 = P; d.T2 = T; } else { d.P3 = P; d.T3 = T; }
+                ++n;
+            }
+        }
+    } else if (o < Lt::O_NU) {
+        const int t = o - Lt::O_A;
+        const int l = (t >= 3) ? 2 : ((t >= 1) ? 1 : 0);
+        const int m = t - l * (l + 1) / 2;
+        if (IC) {
+            d.c_self = (l == m) ? -0.5f : -1.0f;
+        } else {
+            d.c_self = -SMOE_INV_SQ;
+            d.P1 = Pk + 4u * (uint32_t)(Lt::O_MU + l);
+            d.T1 = Tk + 4u * (uint32_t)(Lt::O_MU + m);
+        }
+        if (l == m && use_det) { d.TR = Tk + 4u * Lt::O_PI; d.PR = Pk + 4u * (uint32_t)(Lt::O_A + l * (l + 1) / 2 + l); }
+    }
+    return d;
+}
+
+// the addresses are byte offsets from the start of the workgroup's dynamic LDS
+__device__ __forceinline__ float lds_f32(const float* __restrict__ lds, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + byte_off);
+}
+
+__device__ __forceinline__ float eval_slot_desc(const float* __restrict__ lds, const SlotDesc& d, float tot) {
+    const float t1 = lds_f32(lds, d.T1), t2 = lds_f32(lds, d.T2), t3 = lds_f32(lds, d.T3), tr = lds_f32(lds, d.TR);
+    const float p1 = lds_f32(lds, d.P1), p2 = lds_f32(lds, d.P2), p3 = lds_f32(lds, d.P3), pr = lds_f32(lds, d.PR);
+    const bool act = (lds_f32(lds, d.FLAG) != 0.0f) && (lds_f32(lds, d.PIV) > 0.0f);          // smoe.py:480,738
+    float g = d.c_self * tot;
+    g = fmaf(p1, t1, g);
+    g = fmaf(p2, t2, g);
+    g = fmaf(p3, t3, g);
+    return fmaf(act ? fast_rcp(pr) : 0.0f, tr, g);
+}
+
 // ---------------------------------------------------------------------------
 // LDS carve-up shared by the fit and forward kernels
 // ---------------------------------------------------------------------------
@@ -657,6 +733,17 @@ struct Tile {
     __host__ __device__ static int off_coords() { return 0; }
     __host__ __device__ static int off_par(int N, int CR) { return round_up(CR * N, 4); }
     __host__ __device__ static int off_mv(int N, int CR) { return off_par(N, CR) + NB * Lt::LP_STRIDE; }
+    // The wavefront-per-block tiling turns the raw sums into gradients on the OWNER side when the blocks are small (eval_slot_desc):
+    // per block a table of 12-dword descriptors, one per packed parameter, built once per launch.  (The 16-lane tiling
+    // owns three slots per lane and keeps the per-lane transform before the reduction, finish_partials: measured there.)
+    static constexpr bool OWNER_POST = (G >= 64);        // (32 lanes per block: measured, no gain -- 209.5 vs 209.9 Gpx-it/s at 4 096 blocks)
+    static constexpr int DESC_DW = 12;
+    static constexpr int DESC_STRIDE = OWNER_POST ? Lt::NPAR * DESC_DW : 0;
+    static constexpr int TOT_STRIDE = round_up(Lt::NSLOT, 4);          // published raw totals of one block (in the scratch)
+    static_assert(!OWNER_POST || BPW * TOT_STRIDE <= CH * ROW, "the published totals must fit into the reduction scratch");
+    // the descriptor tables sit behind everything else (FitArgs::desc_off, set by the launcher when the blocks are small:
+    // few pixels per lane, LDS to spare; 0 = keep the per-lane transform)
+    __host__ __device__ static bool wants_owner_post(int N) { return OWNER_POST && N <= 8 * G; }
     __host__ __device__ static int off_scratch(int N, int CR) { return off_mv(N, CR) + NB * MV_STRIDE; }
     __host__ __device__ static int off_tgt(int N, int CR) { return off_scratch(N, CR) + WAVES * CH * ROW; }
     __host__ __device__ static int off_lw(int N, int CR) { return off_tgt(N, CR) + NB * tgt_stride(N); }
@@ -1059,6 +1146,9 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     float* s_par = lds + T::off_par(N, CR) + lb * Lt::LP_STRIDE;
     float* s_mv = lds + T::off_mv(N, CR) + lb * T::MV_STRIDE;
     float* s_scratch = lds + T::off_scratch(N, CR) + wave * (T::CH * T::ROW);
+    const bool owner_post = T::OWNER_POST && a.desc_off > 0;
+    float* s_desc = lds + a.desc_off + lb * T::DESC_STRIDE;              // owner_post: gradient descriptors of the block's slots
+    float* s_tot = s_scratch + grp * T::TOT_STRIDE;                      // OWNER_POST: published raw totals (scratch, after the reduction)
     const float* s_tgt = lds + T::off_tgt(N, CR) + lb * T::tgt_stride(N);
     const float* s_lw = lds + T::off_lw(N, CR) + lb * T::lw_stride(N);
     const bool has_lw = a.loss_w != nullptr;
@@ -1250,6 +1340,27 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     if (has_quant) refresh_quantised_image();
     const float* s_img = (QUANT && has_quant) ? s_q : s_par;      // what the graph is built on (QUANT: the quantised image)
     const bool patch_pis = !QUANT && (a.kc.qpis != 0);               // default kernels: quantised pis from the K extra floats
+    if (owner_post) {
+        // one descriptor per packed parameter of the block (byte offsets from the start of the LDS), built by its owner
+        const uint32_t tot_off = (uint32_t)((s_tot - lds) * sizeof(float));
+        const uint32_t img_off = (uint32_t)((s_img - lds) * sizeof(float));
+        const uint32_t par_off = (uint32_t)((s_par - lds) * sizeof(float));
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = T::slot_of(sub, s);
+            if (j < Lt::NPAR) {
+                const SlotDesc d = build_slot_desc<D, C, K, IC>(j, tot_off, img_off, par_off, patch_pis, a.kc.use_det != 0);
+                float4* o = reinterpret_cast<float4*>(s_desc + j * T::DESC_DW);
+                o[0] = make_float4(d.c_self, d.pub_scale, __uint_as_float(d.T1), __uint_as_float(d.T2));
+                o[1] = make_float4(__uint_as_float(d.T3), __uint_as_float(d.TR), __uint_as_float(d.P1), __uint_as_float(d.P2));
+                o[2] = make_float4(__uint_as_float(d.P3), __uint_as_float(d.PR), __uint_as_float(d.FLAG), __uint_as_float(d.PIV));
+            } else if (j == Lt::S_LOSS) {
+                s_par[Lt::LP_ZERO] = 0.0f;
+                s_par[Lt::LP_ONE] = 1.0f;
+            }
+        }
+        wave_lds_sync();
+    }
 
     float b1p = a.b1p, b2p = a.b2p;
     const KernelConsts kc = a.kc;
@@ -1333,7 +1444,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             }
             if (HL > 0) complete_const<D, C, K, HL, IC>(R, xc, acc);
         }
-        {
+        if (!owner_post) {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
             R2.load(s_img);
             if (patch_pis) {
@@ -1345,6 +1456,57 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 
         float total[T::SPL];
         reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
+
+        if (owner_post) {
+            // raw sums -> gradients on the owner side: publish the raw totals in the (now free) scratch, then every owner
+            // evaluates the descriptor of its slot (eval_slot_desc)
+            SlotDesc dsc[T::SPL];
+#pragma unroll
+            for (int s = 0; s < T::SPL; ++s) {
+                int j = T::slot_of(sub, s);
+                asm volatile("" : "+v"(j));                  // keep the descriptor address out of the registers live across the loop
+                const int jc = (j < Lt::NPAR) ? j : 0;
+                const float4* q = reinterpret_cast<const float4*>(s_desc + jc * T::DESC_DW);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                dsc[s].c_self = q0.x; dsc[s].pub_scale = q0.y; dsc[s].T1 = __float_as_uint(q0.z); dsc[s].T2 = __float_as_uint(q0.w);
+                dsc[s].T3 = __float_as_uint(q1.x); dsc[s].TR = __float_as_uint(q1.y); dsc[s].P1 = __float_as_uint(q1.z); dsc[s].P2 = __float_as_uint(q1.w);
+                dsc[s].P3 = __float_as_uint(q2.x); dsc[s].PR = __float_as_uint(q2.y); dsc[s].FLAG = __float_as_uint(q2.z); dsc[s].PIV = __float_as_uint(q2.w);
+                if (j < Lt::NPAR) s_tot[j] = total[s] * dsc[s].pub_scale;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int s = 0; s < T::SPL; ++s) {
+                const int j = T::slot_of(sub, s);
+                if (j < Lt::NPAR) total[s] = eval_slot_desc(lds, dsc[s], total[s]);
+            }
+            if (kc.radial) {
+                // radial_as (smoe.py:714-719): every diagonal slot of a kernel receives the trace of dL/dA
+                wave_lds_sync();
+#pragma unroll
+                for (int s = 0; s < T::SPL; ++s) {
+                    const int j = T::slot_of(sub, s);
+                    if (j < Lt::NPAR) s_tot[j] = total[s];
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int s = 0; s < T::SPL; ++s) {
+                    const int j = T::slot_of(sub, s);
+                    if (j < Lt::NPAR) {
+                        const int k = j / Lt::PK, o = j - k * Lt::PK;
+                        bool diag = false;
+#pragma unroll
+                        for (int l = 0; l < D; ++l) diag = diag || (o == Lt::O_A + tri_index(l, l));
+                        if (diag) {
+                            float tr = 0.0f;
+#pragma unroll
+                            for (int l = 0; l < D; ++l) tr += s_tot[k * Lt::PK + Lt::O_A + tri_index(l, l)];
+                            total[s] = tr;
+                        }
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
 
         // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
         const float bias = __builtin_amdgcn_sqrtf(1.0f - b2p) * fast_rcp(1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
@@ -1750,10 +1912,14 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, false);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    FitArgs aa = a;
+    size_t shm_all = shm;
+    aa.desc_off = 0;
+    if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }
 
@@ -1785,10 +1951,14 @@ hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
         hl = 2;
     }
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, true);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    FitArgs aa = a;
+    size_t shm_all = shm;
+    aa.desc_off = 0;
+    if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }
 
@@ -1817,10 +1987,14 @@ hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1, false, false, true>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, false, true>; hl = 2; }
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, false);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    FitArgs aa = a;
+    size_t shm_all = shm;
+    aa.desc_off = 0;
+    if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }
 
@@ -1857,10 +2031,14 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
             hl = 1;
         }
         const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, q);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    FitArgs aa = a;
+    size_t shm_all = shm;
+    aa.desc_off = 0;
+    if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

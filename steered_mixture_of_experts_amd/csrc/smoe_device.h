@@ -56,6 +56,7 @@ struct FitArgs {
     float reg_u;              // u_l1
     const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11] (null otherwise)
     int bh, bw;
+    int desc_off;             // float offset of the owner-side gradient descriptors in the dynamic LDS (set by the launcher; 0 = off)
     KernelConsts kc;
 };
 
