@@ -71,27 +71,22 @@ struct Layout {
 template <int D, int C, int K>
 __device__ __forceinline__ void decode_slot(int j, int b, int& tensor, long& off, int& kern) {
     using Lt = Layout<D, C, K>;
+    // branch-free on purpose (selects instead of a chain of divergent branches): every owner runs this for each of its
+    // slots in the prologue and the epilogue of a launch
     const int k = j / Lt::PK;
     const int o = j - k * Lt::PK;
     const long bk = (long)b * K + k;
     kern = k;
-    if (o == Lt::O_PI) {
-        tensor = 0; off = bk;
-    } else if (o < Lt::O_A) {
-        tensor = 1; off = bk * D + (o - Lt::O_MU);
-    } else if (o < Lt::O_NU) {
-        const int t = o - Lt::O_A;
-        int l = 0;
-        while ((l + 1) * (l + 2) / 2 <= t) ++l;
-        const int m = t - l * (l + 1) / 2;
-        tensor = (l == m) ? 2 : 3;
-        off = (bk * D + l) * D + m;
-    } else if (o < Lt::O_GA) {
-        tensor = 5; off = bk * C + (o - Lt::O_NU);
-    } else {
-        const int t = o - Lt::O_GA;     // l*C + c
-        tensor = 4; off = bk * (D * C) + t;
-    }
+    const int t = o - Lt::O_A;                                        // steering entry: lower triangle, row-major
+    const int l = (t >= 3) ? 2 : ((t >= 1) ? 1 : 0);
+    const int m = t - l * (l + 1) / 2;
+    const bool is_pi = o == Lt::O_PI, is_mu = o < Lt::O_A, is_a = o < Lt::O_NU, is_nu = o < Lt::O_GA;
+    tensor = is_pi ? 0 : (is_mu ? 1 : (is_a ? ((l == m) ? 2 : 3) : (is_nu ? 5 : 4)));
+    off = is_pi ? bk
+        : (is_mu ? bk * D + (o - Lt::O_MU)
+        : (is_a ? (bk * D + l) * D + m
+        : (is_nu ? bk * C + (o - Lt::O_NU)
+        : bk * (D * C) + (o - Lt::O_GA))));
 }
 
 __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
@@ -782,23 +777,19 @@ __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, c
     float* s_coords = lds + T::off_coords();
     float* s_tgt = lds + T::off_tgt(N, CR);
     float* s_lw = lds + T::off_lw(N, CR);
+    // the NB blocks follow each other in global memory AND in LDS: a straight copy of NB * per floats (no per-element
+    // block arithmetic -- a run-time integer division costs ~40 instructions).  Elements past the end of the batch
+    // re-read the last 16 bytes of the array (valid memory; those blocks' results are never stored).
     auto copy_planes = [&](const float* __restrict__ src, float* __restrict__ dst, int per) {
-        // per = floats per block (multiple of 4 on the vector path)
+        const size_t g0 = (size_t)blk0 * per;
+        const size_t gend = (size_t)B * per;
         if ((per & 3) == 0) {
-            const int per4 = per >> 2;
-            for (int i = threadIdx.x; i < T::NB * per4; i += T::THREADS) {
-                const int lb = i / per4;
-                const int rem = i - lb * per4;
-                const int b = min(blk0 + lb, B - 1);
-                reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src + (size_t)b * per)[rem];
-            }
+            const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
+            const size_t last4 = (gend >> 2) - 1;
+            for (int i = threadIdx.x; i < T::NB * (per >> 2); i += T::THREADS)
+                reinterpret_cast<float4*>(dst)[i] = src4[min((g0 >> 2) + (size_t)i, last4)];
         } else {
-            for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) {
-                const int lb = i / per;
-                const int rem = i - lb * per;
-                const int b = min(blk0 + lb, B - 1);
-                dst[i] = src[(size_t)b * per + rem];
-            }
+            for (int i = threadIdx.x; i < T::NB * per; i += T::THREADS) dst[i] = src[min(g0 + (size_t)i, gend - 1)];
         }
     };
     for (int i = threadIdx.x; i < CR * N; i += T::THREADS) s_coords[i] = coords[i];
@@ -1744,7 +1735,11 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     unsigned long long flags[K];                   // influence votes of the full steps (scalar unit), see pixel<>
 #pragma unroll
     for (int k = 0; k < K; ++k) flags[k] = 0ull;
-    auto step = [&](int n, auto voted) {
+    // OUT: the launch wants per-pixel outputs (reconstruction / gate planes / argmax); the loss-only pass of a validation
+    // takes the store-free instance of the loop, two pixels per trip
+    const bool any_out = (a.recon != nullptr) || (a.gate_w != nullptr) || (a.argmax != nullptr) || SSIM;
+    auto step = [&](int n, auto voted, auto want_out) {
+        constexpr bool OUT = decltype(want_out)::value;
         float x[D], t[C];
 #pragma unroll
         for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
@@ -1757,7 +1752,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
         }
-        if (valid_b) {
+        if (OUT && valid_b) {
             if (a.recon != nullptr) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) a.recon[((size_t)b * C + c) * N + n] = o.q[c];
@@ -1780,8 +1775,18 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             }
         }
     };
-    for (int i = 0; i < full; ++i) step(i * G + sub, std::true_type{});
-    if (full < pxl && full * G + sub < N) step(full * G + sub, std::false_type{});
+    if (any_out) {
+        for (int i = 0; i < full; ++i) step(i * G + sub, std::true_type{}, std::true_type{});
+        if (full < pxl && full * G + sub < N) step(full * G + sub, std::false_type{}, std::true_type{});
+    } else {
+        int i = 0;
+        for (; i + 1 < full; i += 2) {
+            step(i * G + sub, std::true_type{}, std::false_type{});
+            step((i + 1) * G + sub, std::true_type{}, std::false_type{});
+        }
+        if (i < full) step(i * G + sub, std::true_type{}, std::false_type{});
+        if (full < pxl && full * G + sub < N) step(full * G + sub, std::false_type{}, std::false_type{});
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[Lt::S_CNT + k] += ((flags[k] >> lane) & 1ull) ? 1.0f : 0.0f;
 
