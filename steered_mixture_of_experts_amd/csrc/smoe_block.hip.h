@@ -695,8 +695,12 @@ struct Tile {
     // scratch (64 floats + pad); a row is read back in units of U floats, one unit per lane, RPR rows per round:
     //   G = 16, 32: unit = the G partials of one block, lane (grp, sub) sums row `sub` of block `grp`;
     //   G = 64    : unit = half a row, lanes 2r and 2r+1 sum the halves of row r and exchange them (DPP quad_perm).
-    static constexpr int U = (G >= 32) ? 32 : G;
-    static constexpr int RPR = U;                       // rows per round
+    //               parameter-rich triples (>= 90 slots: large blocks, where LDS decides how many wavefronts a CU holds):
+    //               quarter rows, four lanes per row and two exchanges -- half the scratch (16x16x4 / 1 024-pixel blocks then
+    //               fit four workgroups per CU instead of three)
+    static constexpr int U = (G == 64) ? ((Lt::NSLOT >= 90) ? 16 : 32) : G;
+    static constexpr int UL = G / U;                    // lanes that share a row (1, 2 or 4)
+    static constexpr int RPR = 64 / UL / (64 / G);      // rows per round = lanes of a block / lanes per row
     static constexpr int NROUND = (Lt::NSLOT + RPR - 1) / RPR;
     // rows of one pass = rows of the scratch: one round per pass.  (Two rounds per pass -- one LDS hand-off for 64
     // slots -- were measured: 1 024 blocks +2 %, but the 17 KB of scratch per wavefront cost the 1 024-pixel blocks a
@@ -705,11 +709,11 @@ struct Tile {
     static constexpr int RPP = CH / RPR;                // rounds per pass
     static constexpr int ROW = 64 + 4;                  // padded row (bank-conflict-free b128 reads)
     static constexpr int NCHUNK = (Lt::NSLOT + CH - 1) / CH;
-    // slots owned per lane.  G = 64: both lanes of a pair hold a round's totals, lane 2r owns the slot of the even
-    // rounds, lane 2r+1 that of the odd rounds
-    static constexpr int SPL = (G == 64) ? (NROUND + 1) / 2 : NROUND;
+    // slots owned per lane: all UL lanes of a row hold its total after the exchange; lane u of them owns the slot of the
+    // rounds q with q % UL == u
+    static constexpr int SPL = (NROUND + UL - 1) / UL;
     __host__ __device__ static constexpr int slot_of(int sub, int s) {
-        return (G == 64) ? ((2 * s + (sub & 1)) * RPR + (sub >> 1)) : (sub + s * G);
+        return (UL * s + (sub % UL)) * RPR + sub / UL;
     }
     static constexpr int THREADS = WAVES * 64;
     static_assert(NB * K * ParamTile<D, C, K>::PER_KERNEL <= WAVES * CH * ROW, "the parameter tile of a workgroup is staged in the reduction scratch");
@@ -855,8 +859,12 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
                                              int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
     using T = Tile<D, C, K, G, WAVES>;
     using Lt = Layout<D, C, K>;
-    const int rho = (G == 64) ? (lane >> 1) : (lane % G);              // the lane's row within a round
-    const int base = (G == 64) ? (lane & 1) * T::U : (lane / G) * G;   // its unit within the row
+    // (opaque lane index: the row / unit / scratch addresses derived from it are loop invariant, and hoisted out of the
+    // iteration loop they stay live across the pixel loop -- the 16x16x4 kernel sits at 253 of 256 VGPRs)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int rho = (G == 64) ? (ln / T::UL) : (ln % G);                      // the lane's row within a round
+    const int base = (G == 64) ? (ln % T::UL) * T::U : (ln / G) * G;          // its unit within the row
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) total[s] = 0.0f;
 #pragma unroll
@@ -865,7 +873,7 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
 #pragma unroll
         for (int a = 0; a < T::CH; ++a) {
             const int j = c * T::CH + a;
-            if (j >= FIRST && j < Lt::NSLOT) scratch_wave[a * T::ROW + lane] = acc[j];
+            if (j >= FIRST && j < Lt::NSLOT) scratch_wave[a * T::ROW + ln] = acc[j];
         }
         wave_lds_sync();
         float tot[T::RPP];
@@ -892,9 +900,11 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
             if (q * T::RPR >= Lt::NSLOT || (q + 1) * T::RPR <= FIRST) continue;
             float t = tot[r];
             if (G == 64) {
-                // the other half of the row sits in the neighbouring lane: quad_perm [1,0,3,2], both lanes get the sum
+                // the other parts of the row sit in the neighbouring lanes: quad_perm [1,0,3,2] (then [2,3,0,1]); every
+                // lane of the group ends up with the sum
                 t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xf, 0xf, true));
-                if ((q & 1) == (lane & 1)) total[q >> 1] = t;
+                if (T::UL == 4) t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xf, 0xf, true));
+                if ((q % T::UL) == (ln % T::UL)) total[q / T::UL] = t;
             } else {
                 total[q] = t;
             }
@@ -1623,12 +1633,14 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     const FitArgs* ka = (const FitArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));
     if (valid_b) {
+        int bo = b;
+        asm volatile("" : "+v"(bo));       // not the prologue's slot offsets kept live across the iteration loop (4 VGPRs)
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
                 int tensor, kern; long off;
-                decode_slot<D, C, K>(j, b, tensor, off, kern);
+                decode_slot<D, C, K>(j, bo, tensor, off, kern);
                 pick(ka->p, tensor)[off] = s_par[j];
                 pick(ka->m, tensor)[off] = s_mv[2 * j];
                 pick(ka->v, tensor)[off] = s_mv[2 * j + 1];
