@@ -862,7 +862,7 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
     // (opaque lane index: the row / unit / scratch addresses derived from it are loop invariant, and hoisted out of the
     // iteration loop they stay live across the pixel loop -- the 16x16x4 kernel sits at 253 of 256 VGPRs)
     int ln = lane;
-    asm volatile("" : "+v"(ln));
+    if constexpr (G == 64) asm volatile("" : "+v"(ln));       // (the 16-lane kernels have the registers and lose 1 % to the recomputation)
     const int rho = (G == 64) ? (ln / T::UL) : (ln % G);                      // the lane's row within a round
     const int base = (G == 64) ? (ln % T::UL) * T::U : (ln / G) * G;          // its unit within the row
 #pragma unroll
