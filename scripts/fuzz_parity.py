@@ -19,22 +19,32 @@ QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), u
 
 def one_case(rng, idx):
     d = 3 if rng.random() < float(os.environ.get('FUZZ_P3D', '0.2')) else 2
-    C = 3 if (d == 3 or rng.random() < 0.5) else 1
+    C = 3 if ((d == 3 and rng.random() < 0.7) or (d == 2 and rng.random() < 0.5)) else 1
     if d == 3:
-        shape, kpd = (int(rng.integers(5, 17)), int(rng.integers(5, 17)), int(rng.integers(2, 6))), [2, 2, 1]
+        shape = (int(rng.integers(5, 17)), int(rng.integers(5, 17)), int(rng.integers(2, 6)))
+        kpd = [2, 2, 1]
     else:
         shape = (int(rng.integers(5, 41)), int(rng.integers(5, 41)))
         kpd = [2, 4] if (C == 3 and rng.random() < 0.3) or (C == 1 and rng.random() < 0.3) else [2, 2]
+    generic = rng.random() < float(os.environ.get('FUZZ_PGENERIC', '0.35'))
+    if generic or (d == 3 and C == 1):
+        # any kernel grid (csrc/smoe_variants.def, basic instantiations: margin loss, quantize_pis, train_inverse_cov)
+        grids = {(2, 1): [[1, 1], [1, 2], [3, 1], [2, 3], [3, 3], [3, 4], [4, 4]],
+                 (2, 3): [[1, 1], [2, 1], [1, 3], [3, 2], [3, 3]],
+                 (3, 1): [[1, 1, 1], [2, 1, 1], [1, 3, 1], [2, 2, 1], [3, 2, 1], [2, 2, 2]],
+                 (3, 3): [[1, 1, 1], [1, 2, 1], [3, 1, 1], [1, 3, 2], [2, 2, 2]]}[(d, C)]
+        kpd = grids[int(rng.integers(len(grids)))]
+        generic = True
     yuv = bool(C == 3 and rng.random() < 0.7)
     kw = {}
     if rng.random() < 0.4:
         kw["train_inverse_cov"] = True
-    mode = int(rng.choice([0, 0, 2, 3]))
+    mode = 0 if generic else int(rng.choice([0, 0, 2, 3]))
     if mode:
         kw.update(quantization_mode=mode, quantize_pis=True, **QKW)
     elif rng.random() < 0.5:
         kw["quantize_pis"] = True
-    ssim = d == 2 and rng.random() < 0.3
+    ssim = d == 2 and not generic and rng.random() < 0.3
     if ssim:
         kw["ssim_opt"] = True
     if C == 3 and yuv and rng.random() < 0.3:
@@ -47,7 +57,7 @@ def one_case(rng, idx):
     if rng.random() < 0.15 and mode != 3:
         kw["radial_as"] = True
     B = int(rng.integers(3, 40))
-    tiling = int(rng.choice([0, 16, 64]))
+    tiling = int(rng.choice([0, 16, 32, 64]))
     desc = dict(idx=idx, shape=shape, C=C, kpd=kpd, yuv=yuv, B=B, tiling=tiling, **kw)
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 1000 + idx, **kw)
     dd = len(shape)
@@ -101,7 +111,9 @@ def one_case(rng, idx):
         if clean.any():
             for name in o.PARAM_NAMES:
                 g = ref["grads"][name][clean]
-                err = np.abs(m[name][clean] / 0.1 - g).max() / (np.abs(g).max() + 1e-30)
+                # (one kernel per block: the gradients of pis / musX / A vanish identically; rounding residue vs the expert scale)
+                floor = np.abs(ref["grads"]["nu_e"][clean]).max() if K == 1 else 0.0
+                err = np.abs(m[name][clean] / 0.1 - g).max() / (max(np.abs(g).max(), floor) + 1e-30)
                 if err > worst[1]:
                     worst = (name, float(err))
         ok = (lerr < 5e-5) and (worst[1] < 2e-4)
