@@ -255,6 +255,7 @@ class Smoe:
         self._diverged = torch.zeros((self.B,), dtype=torch.int32, device=dev)
         self._loss0 = None
         self._best_loss_blocks = None
+        self._sampl_prob = None              # per-pixel sampling probabilities of the last reconstruction pass (smoe.py:906-907)
 
         # -- histories (smoe.py:183-199) -------------------------------------------------
         self.losses, self.mses, self.num_pis, self.num_svs = [], [], [], []
@@ -333,13 +334,14 @@ class Smoe:
                     with_quantized_params=False, sampling_percentage=100, with_inc=False, train_inc=False,
                     thr_sv=None, use_loss_mask=False):
         """One pass over every block (smoe.py:1606-1793).  Returns (loss, mse, num_pi, num_sv)."""
-        if sampling_percentage != 100:
-            raise NotImplementedError("pixel sub-sampling is not part of the hot path")
         if with_inc or train_inc:
             raise NotImplementedError("kernel adding is out of scope")
         self.valid = False
         self._make_engine(pis_l1, u_l1)
         eng = self._engine
+        sub_w = None
+        if train and not self.ssim_opt and sampling_percentage < 100:       # smoe.py:1664-1667
+            sub_w = self._sample_pixels(sampling_percentage)
         if with_quantized_params:
             # smoe.py:1688-1689: the rescaled parameters are fed over the masked-parameter tensors;
             # the kernel lists are not touched (smoe.py:1763)
@@ -359,7 +361,8 @@ class Smoe:
             assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
             loss = torch.empty((self.B,), dtype=torch.float32, device=eng.device)
             sse = torch.empty((self.B,), dtype=torch.float32, device=eng.device)
-            eng.fit(self._target, self._params, self._state, self._active, 1, loss_w=self._loss_w,
+            eng.fit(self._target, self._params, self._state, self._active, 1,
+                    loss_w=self._loss_w if sub_w is None else sub_w,
                     diverged=self._diverged, loss0=self._loss0, loss_out=loss, sse_out=sse)
         else:
             out = eng.forward(self._target, self._params, self._active, loss_w=self._loss_w,
@@ -368,9 +371,36 @@ class Smoe:
             loss, sse = out["loss"], out["sse"]
             if update_reconstruction:
                 self._stitch(out)
+                # smoe.py:906-907,1768-1769: per-pixel sampling probabilities of the next sub-sampled passes
+                err = ((out["recon"] - self._target) ** 2).mean(dim=1)                  # (B, N)
+                self._sampl_prob = err / err.sum(dim=1, keepdim=True).clamp_min(1e-30)
         loss_val, mse_val, num_pi = self._global(loss, sse)
         self._last_block_loss = loss
         return loss_val, mse_val, num_pi, 0
+
+    def _sample_pixels(self, sampling_percentage):
+        """Pixel sub-sampling (smoe.py:1664-1667): every block trains on round(N * p / 100) pixels drawn without
+        replacement with the error-proportional probabilities of the last reconstruction pass (smoe.py:906-907).  The
+        reference feeds only the drawn pixels; here they get the loss weight N / n (the others 0), which gives the same
+        loss and the same gradients -- `mean` over the n drawn pixels.  Draws: exponential-race keys (the successive-
+        sampling law of numpy's `choice(replace=False, p=...)`, another random stream).  Deviation: the kernel list is
+        pruned by the influence over ALL pixels of the block (a superset of the reference's list)."""
+        if getattr(self, "_sampl_prob", None) is None:
+            self.run_batched(train=False, update_reconstruction=True)
+        B, N = self._sampl_prob.shape
+        n = max(1, int(round(N * sampling_percentage / 100.0)))
+        gen = getattr(self, "_sample_gen", None)
+        if gen is None:
+            gen = self._sample_gen = torch.Generator(device=self._sampl_prob.device)
+            gen.manual_seed(20260000 + self.rank)
+        u = torch.rand((B, N), generator=gen, device=self._sampl_prob.device, dtype=torch.float32).clamp_min(1e-30)
+        keys = -torch.log(u) / self._sampl_prob.clamp_min(1e-12)          # smallest keys win
+        idx = torch.topk(keys, n, dim=1, largest=False).indices
+        w = torch.zeros((B, N), dtype=torch.float32, device=self._sampl_prob.device)
+        w.scatter_(1, idx, float(N) / float(n))
+        if self._loss_w is not None:
+            w = w * self._loss_w
+        return w.contiguous()
 
     def _assemble(self, out):
         """Full-image reconstruction / argmax / gate arrays from one pass's device outputs (smoe.py:1719-1783)."""
@@ -424,8 +454,9 @@ class Smoe:
         if optimizer1:
             self.set_optimizer(optimizer1, optimizer2, optimizer3, grad_clip_value_abs=grad_clip_value_abs)
         assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
-        if sampling_percentage != 100 or with_inc or train_inc or not train_orig:
-            raise NotImplementedError("sampling / kernel-adding options are outside the hot path")
+        if with_inc or train_inc or not train_orig:
+            raise NotImplementedError("kernel-adding options are outside the hot path")
+        sampling = (sampling_percentage < 100) and not self.ssim_opt
         self._make_engine(pis_l1, u_l1)
         eng = self._engine
 
@@ -460,8 +491,11 @@ class Smoe:
             while i < num_iter:
                 # run up to the next validation / kernel-list boundary in ONE launch
                 nxt = min(num_iter, (i // val_iter + 1) * val_iter, (i // ukl_iter + 1) * ukl_iter)
+                if sampling:
+                    nxt = i + 1                                               # a fresh pixel draw per pass (smoe.py:1664-1667)
                 n = nxt - i
-                eng.fit(self._target, self._params, self._state, self._active, n, loss_w=self._loss_w,
+                eng.fit(self._target, self._params, self._state, self._active, n,
+                        loss_w=self._sample_pixels(sampling_percentage) if sampling else self._loss_w,
                         diverged=self._diverged, loss0=self._loss0)
                 i = nxt
                 self.iter += n

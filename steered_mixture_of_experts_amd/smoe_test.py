@@ -8,7 +8,7 @@ three Adam optimizers with ``base_lr``, ``base_lr/lr_div``, ``base_lr*lr_mult``
 ``--mode blocks`` (default): every ``-bz`` block is an independent model with ``-k`` kernels per axis
 (the per-block hot path).  ``--mode shared``: the reference's whole-image fit -- ``-k`` is the GLOBAL
 kernel grid and ``-bz`` the pixel batch of a pass.  Flags of features that are not built (kernel
-adding, support vectors, motion models, sampling; batch overlap outside
+adding, support vectors, motion models; batch overlap outside
 ``--mode shared``, SSIM outside ``--mode blocks``) are
 accepted for command-line compatibility but must keep their inactive values.
 """
@@ -91,7 +91,7 @@ def build_parser():
 def main(args):
     if len(args.bit_depths) != 5:
         raise ValueError("Number of bit depths must be five!")                        # smoe_test.py:24-25
-    inactive = {"inc_steps": 0, "sampling_percentage": 100,
+    inactive = {"inc_steps": 0,
                 "svreg": 0, "hpc_mode": False,
                 "train_svs": False, "train_trafo": False,
                 "only_rec_from_checkpoint": False, "checkpoint_path": None}
@@ -99,6 +99,8 @@ def main(args):
         if getattr(args, name) != val:
             raise NotImplementedError(f"--{name}={getattr(args, name)!r}: this feature is outside the per-block hot path "
                                       "(SURVEY section 8) and is not built")
+    if args.sampling_percentage != 100 and args.mode == 'shared':
+        raise NotImplementedError("--sampling_percentage is built for --mode blocks")
     if args.overlap_of_batches and args.mode != 'shared':
         raise NotImplementedError("--overlap_of_batches needs --mode shared (independent blocks have no neighbours)")
     if args.quantization_mode >= 2:                                                   # smoe_test.py:36-37
@@ -137,8 +139,9 @@ def main(args):
     optimizer3 = Adam(args.base_lr * args.lr_mult)
     smoe.set_optimizer(optimizer1, optimizer2, optimizer3)
     if args.iterations != 0:
+        extra = {"sampling_percentage": args.sampling_percentage} if args.mode == 'blocks' else {}
         smoe.train(args.iterations, val_iter=args.validation_iterations, ukl_iter=args.update_kernel_list_iterations,
-                   pis_l1=args.l1reg)                                                 # smoe_test.py:119-121
+                   pis_l1=args.l1reg, **extra)                                        # smoe_test.py:119-121
     # both modes write the reference's checkpoint schema (utils.save_model; smoe_test.py:248-249)
     quant = args.quantization_mode != 0
     save_model(smoe, args.results_path + "/params_best.pkl", best=True, quantize=quant)

@@ -680,3 +680,47 @@ def test_shared_mode_cli_checkpoint_decodes(tmp_path):
         assert np.array_equal(recon, g.get_reconstruction())          # the same graph: inverse-covariance form, quantised pis
     finally:
         smod._default_engine_factory, smod._default_shared_factory, rec._shared_engine_factory = f1, f2, f3
+
+
+def test_pixel_sub_sampling_is_the_reference_subset_fit():
+    """sampling_percentage < 100 (smoe.py:1664-1667): the reference feeds a random subset of a block's pixels, drawn with the
+    error-proportional probabilities of the last reconstruction pass (smoe.py:906-907); the facade gives the drawn pixels
+    the loss weight N / n instead.  Same loss, same gradients: checked against the restatement run on the subset itself."""
+    img = _image(32, 32, seed=3)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+    s.run_batched(train=False, update_reconstruction=True)
+    prob = s._sampl_prob.numpy()
+    assert prob.shape == (4, 256) and np.allclose(prob.sum(axis=1), 1.0, atol=1e-5)
+    rec = s.get_reconstruction()
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    rb, _ = blk.image_to_blocks(rec, (16, 16))
+    err = ((rb - tb) ** 2).reshape(4, 256, -1).mean(axis=2)
+    assert np.allclose(prob, err / err.sum(axis=1, keepdims=True), rtol=1e-4, atol=1e-9)
+    w = s._sample_pixels(25).numpy()
+    assert ((w > 0).sum(axis=1) == 64).all() and np.allclose(w[w > 0], 4.0)
+    # pixels with larger error are drawn more often
+    hits = np.zeros_like(w)
+    for _ in range(40):
+        hits += s._sample_pixels(25).numpy() > 0
+    hi, lo = prob > np.median(prob, axis=1, keepdims=True), prob <= np.median(prob, axis=1, keepdims=True)
+    assert hits[hi].mean() > hits[lo].mean()
+    # weighted full block == the graph on the subset (loss and every gradient)
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4)
+    p0 = o.init_params(tb, [2, 2])
+    coords = o.block_coords((16, 16))
+    tgt = tb.reshape(4, -1, 1)
+    active = np.ones((4, 4), bool)
+    full = o.forward(p0, tgt, coords, active, cfg, w, np.float64, want_grads=True)
+    for b in range(4):
+        sel = np.flatnonzero(w[b] > 0)
+        cfgs = o.OracleConfig(block_shape=(len(sel), 1), channels=1, kernels=4)
+        pb = {k: v[b:b + 1] for k, v in p0.items()}
+        sub = o.forward(pb, tgt[b:b + 1, sel], coords[sel], active[b:b + 1], cfgs, None, np.float64, want_grads=True)
+        assert np.allclose(full["loss"][b], sub["loss"][0], rtol=1e-10)
+        for k in sub["grads"]:
+            assert np.allclose(full["grads"][k][b], sub["grads"][k][0], rtol=1e-9, atol=1e-14), k
+    # and the training loop runs on fresh draws
+    l0 = s.run_batched(train=False)[0]
+    s.train(6, val_iter=3, sampling_percentage=50)
+    assert s.get_iter() == 6 and s.get_losses()[-1][1] < l0 * 1.05
