@@ -716,6 +716,7 @@ struct Tile {
         return (UL * s + (sub % UL)) * RPR + sub / UL;
     }
     static constexpr int THREADS = WAVES * 64;
+    static constexpr int FWD_PXR = 16;                  // evaluation kernel: pixels per lane it keeps in registers (no staged planes)
     static_assert(NB * K * ParamTile<D, C, K>::PER_KERNEL <= WAVES * CH * ROW, "the parameter tile of a workgroup is staged in the reduction scratch");
     static constexpr int MV_STRIDE = round_up(2 * Lt::NPAR, 4);   // Adam m,v image of one block
     // Distance between the blocks of a wavefront in the target / loss-weight planes.  With 16 lanes per block the two
@@ -775,7 +776,7 @@ struct Tile {
 template <int D, int C, int K, int G, int WAVES, int CR = D>
 __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, const float* __restrict__ target,
                                              const float* __restrict__ loss_w, int B, int N, int blk0,
-                                             float* __restrict__ lds) {
+                                             float* __restrict__ lds, bool planes = true) {
     using T = Tile<D, C, K, G, WAVES>;
     static_assert(T::TGT_PAD == 0, "the staged planes of a workgroup are one contiguous run");
     float* s_coords = lds + T::off_coords();
@@ -797,6 +798,7 @@ __device__ __forceinline__ void stage_inputs(const float* __restrict__ coords, c
         }
     };
     for (int i = threadIdx.x; i < CR * N; i += T::THREADS) s_coords[i] = coords[i];
+    if (!planes) return;
     copy_planes(target, s_tgt, C * N);
     if (loss_w != nullptr) copy_planes(loss_w, s_lw, N);
 }
@@ -1690,7 +1692,22 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     using IO = TileIO<D, C, K, T::NB, T::THREADS>;
     float vp[IO::MAXE];
     IO::fetch(a.p, blk0, B, vp);                   // in flight together with the staging loads
-    stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
+    // Every target is read once: with at most FWD_PXR pixels per lane (a.regt, set by the launcher) a lane takes its
+    // targets / loss weights straight from global memory into registers -- all loads of the workgroup are in flight
+    // together with the parameter tile, and without the staged planes the LDS holds 5+ workgroups per CU
+    constexpr int PXR = T::FWD_PXR;
+    const bool regt = !SSIM && (a.regt != 0);
+    float tr[PXR][C], lwr[PXR];
+    if (regt) {
+#pragma unroll
+        for (int i = 0; i < PXR; ++i) {
+            const int n = min(i * G + sub, N - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) tr[i][c] = a.target[((size_t)b * C + c) * N + n];
+            lwr[i] = has_lw ? a.loss_w[(size_t)b * N + n] : 1.0f;
+        }
+    }
+    stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds, !regt);
     float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
     const int bh = a.bh, bw = a.bw;
     const float* s_Tr = s_ssim;
@@ -1750,14 +1767,11 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     // OUT: the launch wants per-pixel outputs (reconstruction / gate planes / argmax); the loss-only pass of a validation
     // takes the store-free instance of the loop, two pixels per trip
     const bool any_out = (a.recon != nullptr) || (a.gate_w != nullptr) || (a.argmax != nullptr) || SSIM;
-    auto step = [&](int n, auto voted, auto want_out) {
+    auto step_t = [&](int n, auto voted, auto want_out, const float (&t)[C], float lw) {
         constexpr bool OUT = decltype(want_out)::value;
-        float x[D], t[C];
+        float x[D];
 #pragma unroll
         for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
-        const float lw = has_lw ? s_lw[n] : 1.0f;
         PixelOut<D, C, K> o;
         pixel<D, C, K, false, HL, false, IC, decltype(voted)::value>(R, a.kc, x, t, lw, acc, o, nullptr, flags);
         if (SSIM) {
@@ -1787,7 +1801,23 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             }
         }
     };
-    if (any_out) {
+    auto step = [&](int n, auto voted, auto want_out) {              // targets / loss weight of pixel n from the staged planes
+        float t[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
+        step_t(n, voted, want_out, t, has_lw ? s_lw[n] : 1.0f);
+    };
+    if (regt) {
+        // targets in registers: the (at most PXR) steps are unrolled; `full` is uniform, so the votes stay legal
+        auto run = [&](auto want_out) {
+#pragma unroll
+            for (int i = 0; i < PXR; ++i) {
+                if (i < full) step_t(i * G + sub, std::true_type{}, want_out, tr[i], lwr[i]);
+                else if (i < pxl && i * G + sub < N) step_t(i * G + sub, std::false_type{}, want_out, tr[i], lwr[i]);
+            }
+        };
+        if (any_out) run(std::true_type{}); else run(std::false_type{});
+    } else if (any_out) {
         for (int i = 0; i < full; ++i) step(i * G + sub, std::true_type{}, std::true_type{});
         if (full < pxl && full * G + sub < N) step(full * G + sub, std::false_type{}, std::true_type{});
     } else {
@@ -1947,11 +1977,13 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     int hl = 0;
     if (a.hoist >= 1) { kern = forward_kernel<D, C, K, G, WAVES, false, false, false, 1>; hl = 1; }
     if (D == 3 && a.hoist >= 2) { kern = forward_kernel<D, C, K, G, WAVES, false, false, false, (D == 3 ? 2 : 1)>; hl = 2; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    FwdArgs aa = a;
+    aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
+    const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
     return hipGetLastError();
 }
 
@@ -1986,11 +2018,13 @@ hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
     auto kern = ic ? forward_kernel<D, C, K, G, WAVES, false, true, true> : forward_kernel<D, C, K, G, WAVES, false, true>;
     int hl = 0;
     if (a.hoist >= 1) { kern = ic ? forward_kernel<D, C, K, G, WAVES, false, true, true, 1> : forward_kernel<D, C, K, G, WAVES, false, true, false, 1>; hl = 1; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    FwdArgs aa = a;
+    aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
+    const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
     return hipGetLastError();
 }
 
@@ -2022,11 +2056,13 @@ hipError_t launch_fwd_ic(const FwdArgs& a, hipStream_t st) {
     int hl = 0;
     if (a.hoist >= 1) { kern = forward_kernel<D, C, K, G, WAVES, false, false, true, 1>; hl = 1; }
     if (D == 3 && a.hoist >= 2) { kern = forward_kernel<D, C, K, G, WAVES, false, false, true, (D == 3 ? 2 : 1)>; hl = 2; }
-    const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl);
+    FwdArgs aa = a;
+    aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
+    const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
     return hipGetLastError();
 }
 
@@ -2074,7 +2110,9 @@ hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, a);
+        FwdArgs aa = a;
+        aa.regt = 0;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

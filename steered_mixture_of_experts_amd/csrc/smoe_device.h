@@ -73,6 +73,7 @@ struct FwdArgs {
     const float* coords;
     int B, N, update_active;
     int hoist;                // trailing axes whose coordinate is a lane constant (same rule as smoe_fit)
+    int regt;                 // evaluation kernel: targets in registers, no staged planes in LDS (set by the launcher)
     float reg_pi, reg_u;
     const float* ssim_T;
     int bh, bw;
