@@ -1767,13 +1767,28 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     // OUT: the launch wants per-pixel outputs (reconstruction / gate planes / argmax); the loss-only pass of a validation
     // takes the store-free instance of the loop, two pixels per trip
     const bool any_out = (a.recon != nullptr) || (a.gate_w != nullptr) || (a.argmax != nullptr) || SSIM;
-    auto step_t = [&](int n, auto voted, auto want_out, const float (&t)[C], float lw) {
+    // `keep`: non-null = hand the pixel's outputs (q[C], wt[K], argmax as float) back to the caller instead of storing
+    // them (the grouped 16-byte stores of the register path below)
+    auto step_t = [&](int n, auto voted, auto want_out, const float (&t)[C], float lw, float* keep = nullptr) {
         constexpr bool OUT = decltype(want_out)::value;
         float x[D];
 #pragma unroll
         for (int l = 0; l < D; ++l) x[l] = (l < D - HL) ? s_coords[l * N + n] : 0.0f;
         PixelOut<D, C, K> o;
         pixel<D, C, K, false, HL, false, IC, decltype(voted)::value>(R, a.kc, x, t, lw, acc, o, nullptr, flags);
+        if (OUT && keep != nullptr) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) keep[c] = o.q[c];
+            float best = 0.0f;
+            int arg = 255;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                keep[C + k] = o.wt[k];
+                if (o.wt[k] > best) { best = o.wt[k]; arg = k; }
+            }
+            keep[C + K] = __int_as_float(arg);
+            return;
+        }
         if (SSIM) {
 #pragma unroll
             for (int c = 0; c < C; ++c) s_X[c * N + n] = o.q[c];
@@ -1810,10 +1825,59 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     if (regt) {
         // targets in registers: the (at most PXR) steps are unrolled; `full` is uniform, so the votes stay legal
         auto run = [&](auto want_out) {
+            constexpr bool OUT = decltype(want_out)::value;
+            // Outputs: four consecutive steps of a block's G lanes cover 4 G consecutive pixels of every output plane.
+            // The wavefront turns them through its (idle) reduction scratch -- four dword stores per lane in pixel order,
+            // one 16-byte read -- so that every lane writes 16 bytes and a block 4 G contiguous floats per instruction
+            // instead of four G-float segments (all outputs at 65 536 blocks: 125 -> see DESIGN 3.2).
+            // (only while the four kept steps are <= 24 registers: with three channels they cost the loss-only instance of
+            // this kernel a wavefront per SIMD -- 66 -> 84 us -- for 3.9 -> 4.0 TB/s on the output path)
+            constexpr bool GROUP_OK = (C + K + 1) * 4 <= 24;
+            const bool grouped = GROUP_OK && OUT && ((N & 3) == 0) && ((G & 3) == 0);
+            float* xs = s_scratch + grp * (4 * G);
 #pragma unroll
-            for (int i = 0; i < PXR; ++i) {
-                if (i < full) step_t(i * G + sub, std::true_type{}, want_out, tr[i], lwr[i]);
-                else if (i < pxl && i * G + sub < N) step_t(i * G + sub, std::false_type{}, want_out, tr[i], lwr[i]);
+            for (int i0 = 0; i0 < PXR; i0 += 4) {
+                if (grouped && i0 + 3 < full) {
+                    float keep[4][C + K + 1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) step_t((i0 + r) * G + sub, std::true_type{}, want_out, tr[i0 + r], lwr[i0 + r], keep[r]);
+                    const int nb = i0 * G + 4 * sub;                       // first of the lane's four consecutive pixels
+                    auto turn = [&](int slot) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xs[r * G + sub] = keep[r][slot];
+                        wave_lds_sync();
+                        const float4 v = *reinterpret_cast<const float4*>(xs + 4 * sub);
+                        wave_lds_sync();
+                        return v;
+                    };
+                    if (a.recon != nullptr) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float4 v = turn(c);
+                            if (valid_b) *reinterpret_cast<float4*>(a.recon + ((size_t)b * C + c) * N + nb) = v;
+                        }
+                    }
+                    if (a.gate_w != nullptr) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const float4 v = turn(C + k);
+                            if (valid_b) *reinterpret_cast<float4*>(a.gate_w + ((size_t)b * K + k) * N + nb) = v;
+                        }
+                    }
+                    if (a.argmax != nullptr) {
+                        const float4 v = turn(C + K);
+                        const uint32_t w = (uint32_t)__float_as_int(v.x) | ((uint32_t)__float_as_int(v.y) << 8)
+                                         | ((uint32_t)__float_as_int(v.z) << 16) | ((uint32_t)__float_as_int(v.w) << 24);
+                        if (valid_b) *reinterpret_cast<uint32_t*>(a.argmax + (size_t)b * N + nb) = w;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + r;
+                        if (i < full) step_t(i * G + sub, std::true_type{}, want_out, tr[i], lwr[i]);
+                        else if (i < pxl && i * G + sub < N) step_t(i * G + sub, std::false_type{}, want_out, tr[i], lwr[i]);
+                    }
+                }
             }
         };
         if (any_out) run(std::true_type{}); else run(std::false_type{});
@@ -1876,8 +1940,22 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             }
         }
         if (a.argmax != nullptr) {
-            const int first = (newmask != 0u) ? (__ffs(newmask) - 1) : 0;
+            // every lane patches the bytes it wrote itself: four consecutive pixels per lane where the stores were grouped
+            const uint32_t first = (newmask != 0u) ? (uint32_t)(__ffs(newmask) - 1) : 0u;
+            const bool grouped = ((C + K + 1) * 4 <= 24) && regt && ((N & 3) == 0) && ((G & 3) == 0);
             for (int i = 0; i < pxl; ++i) {
+                if (grouped && (i | 3) < full) {
+                    if ((i & 3) == 0) {
+                        uint32_t* p32 = reinterpret_cast<uint32_t*>(a.argmax + (size_t)b * N + i * G + 4 * sub);
+                        const uint32_t w0 = *p32;
+                        uint32_t w = w0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (((w >> (8 * u)) & 255u) == 255u) w = (w & ~(255u << (8 * u))) | (first << (8 * u));
+                        if (w != w0) *p32 = w;
+                    }
+                    continue;
+                }
                 const int n = i * G + sub;
                 if (n < N) {
                     uint8_t* p8 = a.argmax + (size_t)b * N + n;
