@@ -316,7 +316,7 @@ class Smoe:
         self._state = self._engine.new_adam_state(self._params)
 
     # -- passes ----------------------------------------------------------------------------
-    def _global(self, loss, sse):
+    def _global(self, loss, sse, valid_only=False):
         s = self._engine.reduce_scalars(loss, sse, None)
         pis = self._params["pis"]
         if self.quantize_pis:                                        # num_pi_op counts pis_mask = qpis > 0 (smoe.py:480,1012)
@@ -327,7 +327,10 @@ class Smoe:
         s = s.cpu().numpy()
         total_px = float(self.num_blocks) * self.N
         loss_val = s[0] / total_px                                   # smoe.py:1758
-        mse_val = s[1] / (total_px * self.channels) * (2 ** self.precision) ** 2   # smoe.py:1053,1759
+        # smoe.py:1053,1759.  Ragged images (the reference raises, smoe.py:239-241): passes with a reconstruction count the
+        # image's own pixels (run_batched); training passes report the SSE over the padded tiling.
+        mse_px = float(self.num_pixel) if valid_only else total_px
+        mse_val = s[1] / (mse_px * self.channels) * (2 ** self.precision) ** 2
         return float(loss_val), float(mse_val), int(s[2])
 
     def run_batched(self, pis_l1=0, u_l1=0, sv_l1_sub_l2=0, train=True, update_reconstruction=False,
@@ -369,12 +372,16 @@ class Smoe:
                               want_recon=update_reconstruction, want_argmax=update_reconstruction,
                               want_gate=update_reconstruction)
             loss, sse = out["loss"], out["sse"]
+            if update_reconstruction and self._valid is not None:
+                # ragged image: the kernels' SSE runs over the edge-replicated padding too; with the reconstruction at
+                # hand the reported MSE counts the image's own pixels only (equal to get_psnr() on the cropped image)
+                sse = (((out["recon"] - self._target) ** 2) * self._valid[:, None, :]).sum(dim=(1, 2))
             if update_reconstruction:
                 self._stitch(out)
                 # smoe.py:906-907,1768-1769: per-pixel sampling probabilities of the next sub-sampled passes
                 err = ((out["recon"] - self._target) ** 2).mean(dim=1)                  # (B, N)
                 self._sampl_prob = err / err.sum(dim=1, keepdim=True).clamp_min(1e-30)
-        loss_val, mse_val, num_pi = self._global(loss, sse)
+        loss_val, mse_val, num_pi = self._global(loss, sse, valid_only=(not train) and update_reconstruction and self._valid is not None)
         self._last_block_loss = loss
         return loss_val, mse_val, num_pi, 0
 

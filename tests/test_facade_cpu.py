@@ -724,3 +724,16 @@ def test_pixel_sub_sampling_is_the_reference_subset_fit():
     l0 = s.run_batched(train=False)[0]
     s.train(6, val_iter=3, sampling_percentage=50)
     assert s.get_iter() == 6 and s.get_losses()[-1][1] < l0 * 1.05
+
+
+def test_ragged_image_mse_counts_the_image_pixels_only():
+    """on an image that is not a multiple of the block the reported MSE of a reconstruction pass equals the
+    MSE of the cropped reconstruction (what get_psnr() reports), not that of the padded tiling."""
+    img = _image(40, 52, seed=4)                       # 16x16 blocks: padded to 48 x 64
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine)
+    assert s.padded and s.num_pixel == 40 * 52
+    _, mse, _, _ = s.run_batched(train=False, update_reconstruction=True)
+    rec = s.get_reconstruction()
+    want = float(np.mean((rec.astype(np.float64) - img.astype(np.float64)) ** 2)) * (2 ** 8) ** 2
+    assert abs(mse - want) < 1e-6 * want
+    assert abs(s.get_psnr() - (-10 * np.log10(want / 65536.0))) < 1e-6
