@@ -366,3 +366,41 @@ def test_bench_line_keeps_the_driver_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 4096 * 256 * 30 / (d["ms_per_step"] * 30 / 1e3) / 1e6) / d["value"] < 0.02
+
+
+def test_facade_pads_kernel_counts_without_their_own_kernel():
+    """kernels_per_dim = [1, 5]: no (2, 1, 5) instantiation -> the facade runs K = 6 with one prior-zero kernel
+    (smoe.py:480,738 drops it); results follow the restatement at K = 5."""
+    from fake_engine import OracleEngine
+    from steered_mixture_of_experts_amd.smoe import Adam, Smoe
+    b = blk.synthetic_blocks(12, (16, 16), 1, 77)
+    img = blk.blocks_to_image(b, (48, 64), (16, 16))
+
+    def run(factory):
+        s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[1, 5], batch_size=[16, 16], use_determinant=True,
+                 quantize_pis=True, engine_factory=factory)
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+        s.train(8, val_iter=4)
+        return s
+    g, c = run(None), run(OracleEngine)
+    assert g._kp == 6 and g.kernels == 5 and c._kp == 5
+    pg, pc = g.get_params(), c.get_params()
+    for k in pg:
+        assert pg[k].shape == pc[k].shape
+        assert np.abs(pg[k] - pc[k]).max() < 2e-3 * (np.abs(pc[k]).max() + 1e-6), k
+    assert np.allclose(g.get_losses(), c.get_losses(), rtol=1e-3)
+    assert (np.abs(g.get_reconstruction() - c.get_reconstruction()) < 1.5 / 255).mean() > 0.999
+    assert g.get_weight_matrix().shape == c.get_weight_matrix().shape
+
+
+def test_pixel_sub_sampling_on_the_gpu():
+    from steered_mixture_of_experts_amd.smoe import Adam, Smoe
+    b = blk.synthetic_blocks(16, (16, 16), 1, 78)
+    img = blk.blocks_to_image(b, (64, 64), (16, 16))
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+    l0 = s.run_batched(train=False, update_reconstruction=True)[0]
+    w = s._sample_pixels(25)
+    assert ((w > 0).sum(dim=1) == 64).all() and torch.allclose(w[w > 0], torch.tensor(4.0, device=w.device))
+    s.train(20, val_iter=10, sampling_percentage=50)
+    assert s.get_iter() == 20 and s.get_losses()[-1][1] < l0
