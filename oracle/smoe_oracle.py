@@ -328,47 +328,58 @@ def route_quant_grads(grads, back, T):
 
 
 # --------------------------------------------------------------------------
-# SSIM loss (smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d blocks
+# SSIM loss (smoe.py:980-1011 -> ops/image_ops_impl.py:77-233), 2-d and 3-d blocks
 # --------------------------------------------------------------------------
 SSIM_SIZE, SSIM_SIGMA, SSIM_PAD = 11, 1.5, 5                  # image_ops_impl.py:180-181; smoe.py:994
 SSIM_C1, SSIM_C2 = 0.01 ** 2, 0.03 ** 2                       # image_ops_impl.py:74-75,110-111 (max_val = 1)
 
 
-def ssim_window(T=np.float32):
-    """_fspecial_gauss (image_ops_impl.py:132-149): softmax over the 11x11 grid of
-    -0.5 (r^2 + c^2) / sigma^2."""
+def ssim_window(T=np.float32, ndim=2):
+    """_fspecial_gauss (image_ops_impl.py:132-149): softmax over the 11^ndim grid of -0.5 |offset|^2 / sigma^2."""
     c = np.arange(SSIM_SIZE, dtype=T) - T(SSIM_SIZE - 1) / T(2)
     g = np.square(c) * T(-0.5 / SSIM_SIGMA ** 2)
-    g2 = g[None, :] + g[:, None]
-    e = np.exp(g2 - g2.max())
+    if ndim == 2:
+        gn = g[None, :] + g[:, None]
+    else:
+        gn = g[None, None, :] + g[None, :, None] + g[:, None, None]
+    e = np.exp(gn - gn.max())
     return (e / e.sum()).astype(T)
 
 
 def _ssim_reduce(img, win):
-    """reducer (image_ops_impl.py:203-219): VALID depthwise correlation of (B,H,W) with the window."""
-    v = np.lib.stride_tricks.sliding_window_view(img, (SSIM_SIZE, SSIM_SIZE), axis=(1, 2))
-    return np.einsum("bijuv,uv->bij", v, win)
+    """reducer (image_ops_impl.py:203-219): VALID correlation of (B, *spatial) with the window (depthwise_conv2d per
+    channel for images, conv3d per channel for volumes)."""
+    nd = win.ndim
+    v = np.lib.stride_tricks.sliding_window_view(img, (SSIM_SIZE,) * nd, axis=tuple(range(1, nd + 1)))
+    if nd == 2:
+        return np.einsum("bijuv,uv->bij", v, win)
+    return np.einsum("bijkuvw,uvw->bijk", v, win)
 
 
 def ssim_and_grad(q, t, block_shape, T=np.float32, want_grad=False):
-    """custom_ssim on SYMMETRIC-padded blocks (smoe.py:993-998): q, t (B,N,C) -> ssim (B,C) per channel
-    = mean over the bh x bw window positions of luminance * contrast-structure
-    (image_ops_impl.py:110-129,228-230), and d ssim_c / d q (B,N,C) when asked."""
+    """custom_ssim on SYMMETRIC-padded blocks (smoe.py:993-1003): q, t (B,N,C) -> ssim (B,C) per channel
+    = mean over the window positions (one per block pixel) of luminance * contrast-structure
+    (image_ops_impl.py:110-129,228-230), and d ssim_c / d q (B,N,C) when asked.  2-d blocks (images) and 3-d blocks
+    (volumes: ndim = 3, conv3d with the 11x11x11 window, smoe.py:999-1003)."""
     B, N, C = q.shape
-    bh, bw = (int(v) for v in block_shape)
-    assert bh >= SSIM_PAD and bw >= SSIM_PAD, "SYMMETRIC padding by 5 needs blocks of at least 5 pixels per axis"
-    win = ssim_window(T)
+    bs = tuple(int(v) for v in block_shape)
+    nd = len(bs)
+    assert nd in (2, 3) and min(bs) >= SSIM_PAD, "SYMMETRIC padding by 5 needs blocks of at least 5 pixels per axis"
+    win = ssim_window(T, nd)
     c1, c2 = T(SSIM_C1), T(SSIM_C2)
-    pad = ((0, 0), (SSIM_PAD, SSIM_PAD), (SSIM_PAD, SSIM_PAD))
+    pad = ((0, 0),) + ((SSIM_PAD, SSIM_PAD),) * nd
     ssim = np.empty((B, C), dtype=T)
     grad = np.zeros((B, N, C), dtype=T) if want_grad else None
     # index of the block pixel every padded position mirrors
-    ridx = np.pad(np.arange(bh), SSIM_PAD, mode="symmetric")
-    cidx = np.pad(np.arange(bw), SSIM_PAD, mode="symmetric")
-    flat = (ridx[:, None] * bw + cidx[None, :]).ravel()
+    idx = [np.pad(np.arange(b), SSIM_PAD, mode="symmetric") for b in bs]
+    flat = idx[0]
+    for l in range(1, nd):
+        flat = flat[..., None] * bs[l] + idx[l].reshape((1,) * l + (-1,))
+    flat = flat.ravel()
+    sp = tuple(range(1, nd + 1))
     for c in range(C):
-        x = np.pad(q[:, :, c].reshape(B, bh, bw).astype(T), pad, mode="symmetric")
-        y = np.pad(t[:, :, c].reshape(B, bh, bw).astype(T), pad, mode="symmetric")
+        x = np.pad(q[:, :, c].reshape((B,) + bs).astype(T), pad, mode="symmetric")
+        y = np.pad(t[:, :, c].reshape((B,) + bs).astype(T), pad, mode="symmetric")
         mx, my = _ssim_reduce(x, win), _ssim_reduce(y, win)
         num0 = mx * my * T(2)
         den0 = np.square(mx) + np.square(my)
@@ -376,7 +387,7 @@ def ssim_and_grad(q, t, block_shape, T=np.float32, want_grad=False):
         num1 = _ssim_reduce(x * y, win) * T(2)
         den1 = _ssim_reduce(np.square(x) + np.square(y), win)
         cs = (num1 - num0 + c2) / (den1 - den0 + c2)
-        ssim[:, c] = np.mean(lum * cs, axis=(1, 2))
+        ssim[:, c] = np.mean(lum * cs, axis=sp)
         if not want_grad:
             continue
         # per window position: d(lum*cs)/d mu_x, /d E[x^2], /d E[xy]
@@ -387,12 +398,12 @@ def ssim_and_grad(q, t, block_shape, T=np.float32, want_grad=False):
         d_s = -lum * N1 / np.square(D1)
         d_p = lum * T(2) / D1
         # adjoint of the VALID correlation: full correlation of the zero-embedded coefficient maps
-        full = ((0, 0), (SSIM_SIZE - 1, SSIM_SIZE - 1), (SSIM_SIZE - 1, SSIM_SIZE - 1))
-        wf = win[::-1, ::-1]
+        full = ((0, 0),) + ((SSIM_SIZE - 1, SSIM_SIZE - 1),) * nd
+        wf = win[(slice(None, None, -1),) * nd]
         ga = _ssim_reduce(np.pad(d_mx, full), wf)
         gb = _ssim_reduce(np.pad(d_s, full), wf)
         gc = _ssim_reduce(np.pad(d_p, full), wf)
-        gpad = (ga + T(2) * x * gb + y * gc) / T(bh * bw)            # (B, bh+10, bw+10)
+        gpad = (ga + T(2) * x * gb + y * gc) / T(N)                  # (B, *padded block)
         gp = gpad.reshape(B, -1)
         gc_flat = np.zeros((B, N), dtype=T)
         for bi in range(B):

@@ -128,6 +128,30 @@ def custom_ssim_2d(img1, img2):
     return torch.mean(luminance * cs, dim=(0, 1))
 
 
+def custom_ssim_3d(img1, img2):
+    """ops/image_ops_impl.py:77-233 with ndim = 3 for (T0,T1,T2,C) inputs: the 11x11x11 Gaussian (softmax over the sum of
+    the three squared offsets), conv3d per channel (the reference moves the channels to the batch axis,
+    image_ops_impl.py:214-215), VALID, mean of luminance * contrast-structure over the three axes per channel."""
+    dt = img1.dtype
+    c = torch.arange(11, dtype=dt) - 5.0
+    g = (c ** 2) * (-0.5 / 1.5 ** 2)
+    g3 = (g.reshape(1, 1, -1) + g.reshape(1, -1, 1) + g.reshape(-1, 1, 1)).reshape(1, -1)
+    kernel = torch.softmax(g3, dim=1).reshape(1, 1, 11, 11, 11)
+
+    def reducer(x):
+        return torch.nn.functional.conv3d(x.permute(3, 0, 1, 2).unsqueeze(1), kernel)[:, 0].permute(1, 2, 3, 0)
+
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    mean0, mean1 = reducer(img1), reducer(img2)
+    num0 = mean0 * mean1 * 2.0
+    den0 = mean0 ** 2 + mean1 ** 2
+    luminance = (num0 + c1) / (den0 + c1)
+    num1 = reducer(img1 * img2) * 2.0
+    den1 = reducer(img1 ** 2 + img2 ** 2)
+    cs = (num1 - num0 + c2) / (den1 - den0 + c2)
+    return torch.mean(luminance * cs, dim=(0, 1, 2))
+
+
 def _symmetric_pad(img, pad):
     """tf.pad(..., "SYMMETRIC") on the two leading axes of (H,W,C)."""
     import numpy as np
@@ -205,10 +229,18 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
     else:
         loss_pixel = lp.mean()
     if ssim_opt:                                                                 # smoe.py:980-1011
-        bh, bw = block_shape
-        r2 = _symmetric_pad(res.reshape(bh, bw, C), 5)
-        t2 = _symmetric_pad(target.reshape(bh, bw, C), 5)
-        ssim_per_channel = custom_ssim_2d(r2, t2)
+        if len(block_shape) == 3:                                                # smoe.py:999-1003
+            import numpy as np
+            r3, t3 = res.reshape(tuple(block_shape) + (C,)), target.reshape(tuple(block_shape) + (C,))
+            for ax, b in enumerate(block_shape):                                 # tf.pad(..., "SYMMETRIC") on the three axes
+                ii = torch.from_numpy(np.pad(np.arange(b), 5, mode="symmetric"))
+                r3, t3 = r3.index_select(ax, ii), t3.index_select(ax, ii)
+            ssim_per_channel = custom_ssim_3d(r3, t3)
+        else:
+            bh, bw = block_shape
+            r2 = _symmetric_pad(res.reshape(bh, bw, C), 5)
+            t2 = _symmetric_pad(target.reshape(bh, bw, C), 5)
+            ssim_per_channel = custom_ssim_2d(r2, t2)
         if use_yuv:
             ssim = torch.sum(ssim_per_channel * torch.tensor([6.0, 1.0, 1.0], dtype=dt)) / 8
         else:
