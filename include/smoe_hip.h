@@ -69,8 +69,8 @@ typedef struct smoe_config {
     float   u_l1;               /* u_l1 * sum(diag A)                     smoe.py:1044                  */
     int32_t start_pis;          /* normaliser K0 of the l1 term           smoe.py:264,1025              */
     int32_t only_y_gamma;       /* slopes only for channel 0 (gamma_mask) smoe.py:725-729               */
-    int32_t ssim_opt;           /* loss_pixel = 1 - SSIM instead of the margin loss (2-d blocks, every axis >= 5
-                                   pixels): custom_ssim on SYMMETRIC-padded blocks, 11x11 Gaussian, channel
+    int32_t ssim_opt;           /* loss_pixel = 1 - SSIM instead of the margin loss (2-d / 3-d blocks, every axis >= 5
+                                   pixels): custom_ssim on SYMMETRIC-padded blocks, 11x11(x11) Gaussian, channel
                                    weights 6/8,1/8,1/8 (yuv) or the mean; loss_w is ignored as in the reference
                                    smoe.py:929,980-1011, ops/image_ops_impl.py:77-233                     */
     /* Fake-quantised variables inside the graph (smoe.py:474-538): forward, gradients and update_kernel_list see

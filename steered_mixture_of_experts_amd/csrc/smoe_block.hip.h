@@ -763,10 +763,11 @@ struct Tile {
     // later the row pass of the adjoint) and Wb [3][N] (coefficient maps)
     __host__ __device__ static int off_ssim(int N, bool has_lw, int CR, bool hq = false) { return off_qimg(N, has_lw, CR) + (hq ? NB * QI_STRIDE : 0); }
     // G == 16 (16x16 blocks only): the SSIM stage runs in registers (ssim_block16), LDS holds just X per block
-    __host__ __device__ static int ssim_tabs(int bh, int bw) { return (G == 16) ? 0 : round_up(11 * (bh + bw), 4); }
-    __host__ __device__ static int ssim_wave(int N) { return (G == 16) ? BPW * C * N : round_up(C * N + 8 * N, 4); }
-    __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw, bool hq = false) {
-        return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR, hq) + ssim_tabs(bh, bw) + WAVES * ssim_wave(N));
+    // 3-d blocks [bh][bw][bt]: a third tap table, and Wb holds five planes (three axis passes each way)
+    __host__ __device__ static int ssim_tabs(int bh, int bw, int bt = 0) { return (G == 16) ? 0 : round_up(11 * (bh + bw + bt), 4); }
+    __host__ __device__ static int ssim_wave(int N) { return (G == 16) ? BPW * C * N : round_up(C * N + ((D == 3) ? 10 : 8) * N, 4); }
+    __host__ __device__ static size_t bytes_ssim(int N, bool has_lw, int CR, int bh, int bw, bool hq = false, int bt = 0) {
+        return sizeof(float) * (size_t)(off_ssim(N, has_lw, CR, hq) + ssim_tabs(bh, bw, bt) + WAVES * ssim_wave(N));
     }
 };
 
@@ -1163,10 +1164,11 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     float* s_out = s_rng + T::QI_RNG;
     // ssim_opt planes (see Tile::off_ssim)
     float* s_ssim = lds + T::off_ssim(N, has_lw, CR, QUANT);
-    const int bh = a.bh, bw = a.bw;
+    const int bh = a.bh, bw = a.bw, bt = (D == 3) ? a.bt : 0;
     const float* s_Tr = s_ssim;
     const float* s_Tc = s_ssim + bh * 11;
-    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
+    const float* s_Tt = s_Tc + bw * 11;               // 3-d blocks: the taps of the third axis
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw, bt) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
     float* s_Wa = s_X + C * N;
     float* s_Wb = s_Wa + 5 * N;
     float wj[11];                                  // G == 16: this lane's row-pass weights T16[sub][sub + a - 5]
@@ -1177,7 +1179,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                 wj[q] = a.ssim_T[11 * 16 + sub * 11 + q];
             }
         } else {
-            for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+            for (int i = threadIdx.x; i < 11 * (bh + bw + bt); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
         }
     }
     float xc[D];                                   // coordinates of the lane's pixel i = 0 (hoisted axes: all its pixels)
@@ -1422,6 +1424,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     if (i * G + sub < N) recon_step(i * G + sub);
                 wave_lds_sync();
                 if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, true>(s_X, s_tgt, sub, wj, kc.sw);
+                else if constexpr (D == 3) acc[Lt::S_LOSS] = ssim_block3<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, s_Tt, kc.sw, bh, bw, bt, N, lane);
                 else acc[Lt::S_LOSS] = ssim_block<C, true>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, kc.sw, bh, bw, N, lane);
                 // sweep 2: forward again + backward with dL/dq; influence flags as scalar lane-mask votes in the full steps
                 unsigned long long flags[K];
@@ -1709,10 +1712,11 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     }
     stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds, !regt);
     float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
-    const int bh = a.bh, bw = a.bw;
+    const int bh = a.bh, bw = a.bw, bt = (D == 3) ? a.bt : 0;
     const float* s_Tr = s_ssim;
     const float* s_Tc = s_ssim + bh * 11;
-    float* s_X = s_ssim + T::ssim_tabs(bh, bw) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
+    const float* s_Tt = s_Tc + bw * 11;               // 3-d blocks: the taps of the third axis
+    float* s_X = s_ssim + T::ssim_tabs(bh, bw, bt) + wave * T::ssim_wave(N) + ((G == 16) ? grp * (C * N) : 0);
     float* s_Wa = s_X + C * N;
     float* s_Wb = s_Wa + 5 * N;
     float wj[11];
@@ -1723,7 +1727,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
                 wj[q] = a.ssim_T[11 * 16 + sub * 11 + q];
             }
         } else {
-            for (int i = threadIdx.x; i < 11 * (bh + bw); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
+            for (int i = threadIdx.x; i < 11 * (bh + bw + bt); i += T::THREADS) s_ssim[i] = a.ssim_T[i];
         }
     }
     // parameters: one coalesced tile load through the reduction scratch, the owners pick their packed slots
@@ -1899,6 +1903,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     if constexpr (SSIM) {                              // loss_pixel = 1 - SSIM (smoe.py:1006-1010)
         wave_lds_sync();
         if constexpr (G == 16) acc[Lt::S_LOSS] = ssim_block16<C, false>(s_X, const_cast<float*>(s_tgt), sub, wj, a.kc.sw);
+        else if constexpr (D == 3) acc[Lt::S_LOSS] = ssim_block3<C, false>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, s_Tt, a.kc.sw, bh, bw, bt, N, lane);
         else acc[Lt::S_LOSS] = ssim_block<C, false>(s_X, s_tgt, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, N, lane);
     }
     float total[T::SPL];
@@ -2144,10 +2149,10 @@ hipError_t launch_fwd_ic(const FwdArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ssim_opt launches: instantiated for 2-d blocks on the one-block-per-wavefront tiling only
+// ssim_opt launches: 2-d blocks on the 16- and 64-lane tilings, 3-d blocks on the one-block-per-wavefront tiling
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
-    if constexpr (D == 2) {
+    if constexpr (D == 2 || (D == 3 && G == 64)) {
         using T = Tile<D, C, K, G, WAVES>;
         if (G == 16 && (a.bh != 16 || a.bw != 16 || hoist < 1)) return hipErrorNotSupported;   // register path: 16x16 only
         const bool ic = a.kc.inverse_cov != 0;
@@ -2161,7 +2166,7 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
                      : (ic ? fit_kernel<D, C, K, G, WAVES, 1, true, false, true> : fit_kernel<D, C, K, G, WAVES, 1, true>);
             hl = 1;
         }
-        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, q);
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D - hl, a.bh, a.bw, q, (D == 3) ? a.bt : 0);
     FitArgs aa = a;
     size_t shm_all = shm;
     aa.desc_off = 0;
@@ -2178,10 +2183,10 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
 
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
-    if constexpr (D == 2) {
+    if constexpr (D == 2 || (D == 3 && G == 64)) {
         using T = Tile<D, C, K, G, WAVES>;
         if (G == 16 && (a.bh != 16 || a.bw != 16)) return hipErrorNotSupported;
-        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw);
+        const size_t shm = T::bytes_ssim(a.N, a.loss_w != nullptr, D, a.bh, a.bw, false, (D == 3) ? a.bt : 0);
         const bool q = a.kc.qmode >= 2;
         auto kern = q ? (a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, true, true> : forward_kernel<D, C, K, G, WAVES, true, true>)
                       : (a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, false, true> : forward_kernel<D, C, K, G, WAVES, true>);
@@ -2201,9 +2206,9 @@ template <int D, int C, int K, int G, int WAVES>
 size_t lds_bytes(int N, bool has_lw, bool hq) { return Tile<D, C, K, G, WAVES>::bytes(N, has_lw, D, hq); }
 
 template <int D, int C, int K, int G, int WAVES>
-size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw, bool hq) {
-    if (D != 2 || (G == 16 && (bh != 16 || bw != 16))) return (size_t)-1;
-    return Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw, hq);
+size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw, int bt, bool hq) {
+    if (!(D == 2 || (D == 3 && G == 64)) || (G == 16 && (bh != 16 || bw != 16))) return (size_t)-1;
+    return Tile<D, C, K, G, WAVES>::bytes_ssim(N, has_lw, D, bh, bw, hq, (D == 3) ? bt : 0);
 }
 
 template <int D, int C, int K, int G, int WAVES>

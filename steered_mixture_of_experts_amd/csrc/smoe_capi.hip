@@ -157,10 +157,10 @@ const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool ha
         if (h->cfg.ssim_opt) {
             // 16x16 blocks: the register/DPP SSIM stage on the 16-lanes-per-block tiling; any other shape: the
             // LDS stage with one block per wavefront
-            const bool b16 = h->cfg.block_shape[0] == 16 && h->cfg.block_shape[1] == 16;
+            const bool b16 = h->cfg.dim == 2 && h->cfg.block_shape[0] == 16 && h->cfg.block_shape[1] == 16;
             const int g = h->force_g ? h->force_g : (b16 ? 16 : 64);
             if (v[i].G != g) continue;
-            if (v[i].lds_bytes_ssim(h->N, has_lw, h->cfg.block_shape[0], h->cfg.block_shape[1], hq) > 160u * 1024u) continue;
+            if (v[i].lds_bytes_ssim(h->N, has_lw, h->cfg.block_shape[0], h->cfg.block_shape[1], h->cfg.block_shape[2], hq) > 160u * 1024u) continue;
             return &v[i];
         }
         if (v[i].lds_bytes(h->N, has_lw, hq) > 160u * 1024u) continue;
@@ -218,10 +218,11 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built");
     if (cfg->ssim_opt) {
         // the reference pads every axis SYMMETRIC by 5 (smoe.py:993-1003), which TF only accepts for axes of
-        // at least 5 samples; 3-d blocks would need an 11^3 window over a padded time axis and are not built
-        if (cfg->dim != 2) return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt is built for 2-d blocks only");
-        if (cfg->block_shape[0] < 5 || cfg->block_shape[1] < 5)
-            return fail(SMOE_ERR_INVALID, "smoe_create: ssim_opt needs at least 5 pixels per block axis (SYMMETRIC padding by 5)");
+        // at least 5 samples; 3-d blocks take the 11x11x11 window (smoe.py:999-1003, custom_ssim ndim=3)
+        if (cfg->dim != 2 && cfg->dim != 3) return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: ssim_opt is built for 2-d and 3-d blocks");
+        for (int ax = 0; ax < cfg->dim; ++ax)
+            if (cfg->block_shape[ax] < 5)
+                return fail(SMOE_ERR_INVALID, "smoe_create: ssim_opt needs at least 5 pixels per block axis (SYMMETRIC padding by 5)");
     }
     if (!smoe_is_supported(cfg->dim, cfg->channels, cfg->kernels)) {
         char buf[160];
@@ -272,10 +273,11 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * D * 3, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&h->d_partials, sizeof(double) * smoe::reduce_partials_count());
     if (e == hipSuccess && cfg->ssim_opt) {
-        const int bh = cfg->block_shape[0], bw = cfg->block_shape[1];
-        std::vector<float> tabs((size_t)11 * (bh + bw));
+        const int bh = cfg->block_shape[0], bw = cfg->block_shape[1], bt = (cfg->dim == 3) ? cfg->block_shape[2] : 0;
+        std::vector<float> tabs((size_t)11 * (bh + bw + bt));
         ssim_axis_table(bh, tabs.data());
         ssim_axis_table(bw, tabs.data() + (size_t)11 * bh);
+        if (bt) ssim_axis_table(bt, tabs.data() + (size_t)11 * (bh + bw));
         e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
     }
@@ -396,7 +398,7 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.reg_pi = h->cfg.pis_l1 / (float)(h->cfg.start_pis > 0 ? h->cfg.start_pis : h->cfg.kernels);
     a.reg_u = h->cfg.u_l1;
     a.kc = h->kc;
-    a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1];
+    a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1]; a.bt = h->cfg.block_shape[2];
     if (h->cfg.ssim_opt) HIP_TRY(v->fwd_ssim(a, (hipStream_t)stream), "smoe_forward (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fwd_quant(a, (hipStream_t)stream), "smoe_forward (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fwd_ic(a, (hipStream_t)stream), "smoe_forward (inverse covariance) launch");
@@ -429,7 +431,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.reg_u = c.u_l1;
     a.kc = h->kc;
     const int hoist = hoist_level(h, v);
-    a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1];
+    a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1]; a.bt = c.block_shape[2];
     if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fit_ic(a, hoist, (hipStream_t)stream), "smoe_fit (inverse covariance) launch");

@@ -54,8 +54,8 @@ struct FitArgs {
     float clip;
     float reg_pi;             // pis_l1 / start_pis
     float reg_u;              // u_l1
-    const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11] (null otherwise)
-    int bh, bw;
+    const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11], 3-d blocks: Tt [bt][11] (null otherwise)
+    int bh, bw, bt;
     int desc_off;             // float offset of the owner-side gradient descriptors in the dynamic LDS (set by the launcher; 0 = off)
     KernelConsts kc;
 };
@@ -76,7 +76,7 @@ struct FwdArgs {
     int regt;                 // evaluation kernel: targets in registers, no staged planes in LDS (set by the launcher)
     float reg_pi, reg_u;
     const float* ssim_T;
-    int bh, bw;
+    int bh, bw, bt;
     KernelConsts kc;
 };
 
@@ -113,7 +113,7 @@ struct Variant {
     int (*fit_waves_per_cu)(int N, bool has_lw);
     hipError_t (*fit_ssim)(const FitArgs&, int hoist_level, hipStream_t);   // ssim_opt (D == 2, G == 64)
     hipError_t (*fwd_ssim)(const FwdArgs&, hipStream_t);
-    size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw, bool quant_image);
+    size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw, int bt, bool quant_image);
     hipError_t (*readmit_quant)(const ReadmitArgs&, const KernelConsts&, hipStream_t);   // fake-quantised graph
     hipError_t (*fit_quant)(const FitArgs&, int hoist_level, hipStream_t);               // quantization_mode 2 / 3
     hipError_t (*fwd_quant)(const FwdArgs&, hipStream_t);

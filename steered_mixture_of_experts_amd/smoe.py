@@ -171,9 +171,7 @@ class Smoe:
         if self.ssim_opt:
             # loss_pixel = 1 - SSIM (smoe.py:929,980-1011).  The reference's SSIM branch ignores the per-pixel loss
             # weights, so neither a loss mask nor the edge-replicated padding of ragged images can be honoured.
-            if d != 2:
-                raise NotImplementedError("ssim_opt is built for images (2-d blocks); the reference pads the time "
-                                          "axis by 5 as well, which needs at least 5 frames per block")
+            # 3-d blocks: the 11x11x11 window (smoe.py:999-1003), the time axis padded by 5 like the others
             if min(bs) < 5:
                 raise ValueError("ssim_opt pads every block SYMMETRIC by 5: blocks need at least 5 pixels per axis")
             if loss_mask is not None or self.padded:

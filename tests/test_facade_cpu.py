@@ -325,6 +325,24 @@ def test_ssim_opt_fits_one_minus_ssim():
         Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[4, 16], ssim_opt=True, engine_factory=OracleEngine)
 
 
+def test_ssim_opt_on_video_blocks():
+    """3-d blocks: SYMMETRIC pad by 5 on the three axes and the 11x11x11 window (smoe.py:999-1003); the reference's
+    4-frame default cannot be padded, so the blocks here are 6 frames deep."""
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(*[np.linspace(0, 1, n) for n in (16, 16, 6)], indexing="ij"), -1)
+    vid = np.clip(0.5 + 0.3 * np.sin(5 * g[..., :1] + 3 * g[..., 1:2] + 2 * g[..., 2:]) * np.ones(3)
+                  + 0.02 * rng.standard_normal((16, 16, 6, 3)), 0, 1).astype(np.float32)
+    s = Smoe(vid, train_inverse_cov=False, kernels_per_dim=[2, 2, 1], batch_size=[8, 8, 6], use_determinant=True,
+             ssim_opt=True, engine_factory=OracleEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(6, val_iter=3)
+    losses = [v for _, v in s.get_losses()]
+    assert 0.0 < losses[-1] < losses[0] < 1.0
+    with pytest.raises(ValueError):
+        Smoe(vid[:, :, :4], train_inverse_cov=False, kernels_per_dim=[2, 2, 1], batch_size=[8, 8, 4], ssim_opt=True,
+             engine_factory=OracleEngine)
+
+
 @pytest.mark.parametrize("mode,qpis", [(0, True), (2, False), (3, False)])
 def test_fake_quantised_fit_through_the_facade(mode, qpis):
     """quantize_pis / quantization_mode 2, 3 (smoe.py:474-538): the facade trains on the fake-quantised graph

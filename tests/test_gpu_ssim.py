@@ -19,6 +19,10 @@ SSIM_SHAPES = [
     ((8, 8), 1, [2, 2], False),        # block smaller than the 11-tap window: every window wraps both borders
     ((32, 32), 3, [2, 4], True),
     ((16, 16), 1, [2, 4], False),
+    # 3-d blocks (smoe.py:999-1003): the 11x11x11 window, three padded axes
+    ((8, 8, 6), 3, [2, 2, 1], True),
+    ((6, 7, 5), 3, [2, 2, 1], False),  # every axis shorter than the window, nothing a multiple of anything
+    ((8, 8, 8), 3, [2, 1, 2], True),
 ]
 
 
@@ -139,7 +143,7 @@ QKW = dict(bit_depths=(14, 12, 8, 10, 10), lower_bounds=(-60, -.3, -1, 0, -4), u
 
 
 @pytest.mark.parametrize("mode", [2, 3])
-@pytest.mark.parametrize("shape,C,kpd,yuv", [SSIM_SHAPES[0], SSIM_SHAPES[1], SSIM_SHAPES[4]])
+@pytest.mark.parametrize("shape,C,kpd,yuv", [SSIM_SHAPES[0], SSIM_SHAPES[1], SSIM_SHAPES[4], SSIM_SHAPES[6]])
 def test_ssim_on_fake_quantised_variables(shape, C, kpd, yuv, mode):
     """ssim_opt together with quantization_mode 2 / 3: the QUANT instantiation of the SSIM kernels (quantised LDS image,
     masked / routed backward) -- loss and one-step gradients against the restatement, both tilings of 16x16 blocks."""
@@ -186,9 +190,12 @@ def test_ssim_on_fake_quantised_variables(shape, C, kpd, yuv, mode):
 def test_ssim_unsupported_configurations():
     from steered_mixture_of_experts_amd import _lib
     from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
-    with pytest.raises(_lib.SmoeError) as e:
-        BlockEngine(EngineConfig(block_shape=(16, 16, 4), channels=3, kernels=4, ssim_opt=True))
+    with pytest.raises(_lib.SmoeError) as e:       # a triple with the basic kernel set only (csrc/smoe_variants.def)
+        BlockEngine(EngineConfig(block_shape=(8, 8, 6), channels=1, kernels=4, ssim_opt=True))
     assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
+    with pytest.raises(_lib.SmoeError) as e:       # fewer than 5 frames: TF refuses the SYMMETRIC pad
+        BlockEngine(EngineConfig(block_shape=(16, 16, 4), channels=3, kernels=4, ssim_opt=True))
+    assert e.value.code == _lib.SMOE_ERR_INVALID
     with pytest.raises(_lib.SmoeError) as e:
         BlockEngine(EngineConfig(block_shape=(4, 16), channels=1, kernels=4, ssim_opt=True))
     assert e.value.code == _lib.SMOE_ERR_INVALID
@@ -210,4 +217,24 @@ def test_ssim_facade_on_gpu_follows_the_oracle_backed_facade():
     (lg, mg, pg), (lo, mo, po) = runs
     assert abs(lg[0] - lo[0]) < 2e-5 and abs(mg[0] - mo[0]) < 1e-3 * mo[0]
     assert np.allclose(lg, lo, atol=3e-3) and lg[-1] < lg[0] - 0.01
+    assert np.median(np.abs(pg["nu_e"] - po["nu_e"])) < 2e-4
+
+
+def test_ssim_video_facade_on_gpu_follows_the_oracle_backed_facade():
+    from fake_engine import OracleEngine
+    from steered_mixture_of_experts_amd.smoe import Adam, Smoe
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(*[np.linspace(0, 1, n) for n in (32, 32, 6)], indexing="ij"), -1)
+    vid = np.clip(0.5 + 0.3 * np.sin(5 * g[..., :1] + 3 * g[..., 1:2] + 2 * g[..., 2:]) * np.ones(3)
+                  + 0.02 * rng.standard_normal((32, 32, 6, 3)), 0, 1).astype(np.float32)
+    runs = []
+    for factory in (None, OracleEngine):
+        s = Smoe(vid, train_inverse_cov=False, kernels_per_dim=[2, 2, 1], batch_size=[8, 8, 6], use_determinant=True,
+                 use_yuv=True, ssim_opt=True, **({} if factory is None else {"engine_factory": factory}))
+        s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+        s.train(20, val_iter=10)
+        runs.append(([v for _, v in s.get_losses()], s.get_params()))
+    (lg, pg), (lo, po) = runs
+    assert abs(lg[0] - lo[0]) < 2e-5
+    assert np.allclose(lg, lo, atol=3e-3) and lg[-1] < lg[0] - 0.005
     assert np.median(np.abs(pg["nu_e"] - po["nu_e"])) < 2e-4
