@@ -185,7 +185,9 @@ const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks);
 /* Resident wavefronts per CU the runtime grants smoe_fit's kernel for num_blocks (diagnostics). */
 int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks);
 
-/* Force the lanes-per-block tiling (16, 32, 64; 0 = automatic).  Tuning / test hook. */
+/* Force the lanes-per-block tiling (16, 32, 64; 0 = automatic).  128 = the 64-lane kernels with ONE block on both
+ * wavefronts of a workgroup in smoe_fit (the automatic choice for at most 1 024 blocks of the plain margin-loss graph;
+ * other graphs and the evaluation run the plain 64-lane kernel).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1128,10 +1128,17 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // (ssim_block), and the usual fused sweep runs with that gradient instead of the margin loss.
 // QUANT: quantization_mode 2 / 3 (all variables fake-quantised in the graph).
 // IC: train_inverse_cov (symmetric A, maha = r^T A r).
-template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false, bool IC = false>
+// PAIR (few blocks: at most one wavefront per SIMD otherwise; G == 64, two wavefronts per workgroup): the workgroup
+// takes ONE block.  Both wavefronts run the pixel loop, on alternate steps of 64 pixels, and reduce their own
+// accumulators; the second hands its raw totals over through its reduction scratch and the first alone runs the owner
+// phase.  Two workgroup barriers per iteration (totals handed over / parameters written).  A lone wavefront issues one
+// VALU instruction per ~5.6 cycles whatever its instruction-level parallelism (profiles/r02/ubench_valu.txt), two per
+// SIMD one per ~3.2: the second wavefront is nearly free.
+template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false, bool IC = false, bool PAIR = false>
 __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
+    static_assert(!PAIR || (G == 64 && WAVES == 2 && !SSIM && !QUANT), "PAIR: one block on the two wavefronts of a workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int N = a.N;
     const int B = a.B;
@@ -1139,8 +1146,11 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     const int lane = threadIdx.x & 63;
     const int grp = lane / G;
     const int sub = lane - grp * G;
-    const int blk0 = blockIdx.x * T::NB;
-    const int lb = wave * T::BPW + grp;
+    const int blk0 = blockIdx.x * (PAIR ? 1 : T::NB);
+    const int lb = PAIR ? 0 : wave * T::BPW + grp;
+    // PAIR: the wavefront that only sweeps pixels (alternating the role with the workgroup index, so that a SIMD would not
+    // host two owners, measured no difference)
+    const bool helper = PAIR && wave != 0;
     const int b_raw = blk0 + lb;
     const bool valid_b = b_raw < B;
     const int b = valid_b ? b_raw : B - 1;
@@ -1345,8 +1355,9 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     if (has_quant) refresh_quantised_image();
     const float* s_img = (QUANT && has_quant) ? s_q : s_par;      // what the graph is built on (QUANT: the quantised image)
     const bool patch_pis = !QUANT && (a.kc.qpis != 0);               // default kernels: quantised pis from the K extra floats
-    if (owner_post) {
+    if (owner_post && !helper) {
         // one descriptor per packed parameter of the block (byte offsets from the start of the LDS), built by its owner
+        // (PAIR: by the owning wavefront only -- the descriptors point into ITS published totals)
         const uint32_t tot_off = (uint32_t)((s_tot - lds) * sizeof(float));
         const uint32_t img_off = (uint32_t)((s_img - lds) * sizeof(float));
         const uint32_t par_off = (uint32_t)((s_par - lds) * sizeof(float));
@@ -1445,8 +1456,10 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) acc[Lt::S_CNT + k] += ((flags[k] >> lane) & 1ull) ? 1.0f : 0.0f;
             } else {
-                if (has_lw) pixel_loop_train<D, C, K, true, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
-                else pixel_loop_train<D, C, K, false, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, G, sub, acc);
+                // PAIR: pixel n = i * 128 + wave * 64 + sub (the hoisted trailing coordinates stay lane constants)
+                const int gl = PAIR ? 2 * G : G, sl = PAIR ? wave * G + sub : sub;
+                if (has_lw) pixel_loop_train<D, C, K, true, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, gl, sl, acc);
+                else pixel_loop_train<D, C, K, false, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, gl, sl, acc);
             }
             if (HL > 0) complete_const<D, C, K, HL, IC>(R, xc, acc);
         }
@@ -1462,6 +1475,31 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 
         float total[T::SPL];
         reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
+
+        if constexpr (PAIR) {
+            // the helper's totals (linear partial sums, like the accumulators) go to the owners through its own scratch
+            float* s_x = lds + T::off_scratch(N, CR) + (T::CH * T::ROW);
+            if (helper) {
+                wave_lds_sync();                           // its transpose reads are done
+#pragma unroll
+                for (int s = 0; s < T::SPL; ++s) {
+                    const int j = T::slot_of(sub, s);
+                    if (j < Lt::NSLOT) s_x[j] = total[s];
+                }
+            }
+            __syncthreads();
+            if (helper) {
+                __syncthreads();                           // the owners' Adam step: parameters written
+                b1p *= beta1;
+                b2p *= beta2;
+                continue;
+            }
+#pragma unroll
+            for (int s = 0; s < T::SPL; ++s) {
+                const int j = T::slot_of(sub, s);
+                if (j < Lt::NSLOT) total[s] += s_x[j];
+            }
+        }
 
         if (owner_post) {
             // raw sums -> gradients on the owner side: publish the raw totals in the (now free) scratch, then every owner
@@ -1629,6 +1667,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         }
         wave_lds_sync();
         if (has_quant) refresh_quantised_image();
+        if constexpr (PAIR) __syncthreads();
         b1p *= beta1;
         b2p *= beta2;
     }
@@ -1637,7 +1676,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     // live across the iteration loop costs SGPR spills inside it) ------------------------
     const FitArgs* ka = (const FitArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));
-    if (valid_b) {
+    if (valid_b && !helper) {
         int bo = b;
         asm volatile("" : "+v"(bo));       // not the prologue's slot offsets kept live across the iteration loop (4 VGPRs)
 #pragma unroll
@@ -2041,6 +2080,15 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     int hl = 0;
     if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
     if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
+    int nb = T::NB;
+    if constexpr (G == 64 && WAVES == 2) {
+        if (a.pair) {                                  // one block on both wavefronts of the workgroup (see fit_kernel)
+            kern = fit_kernel<D, C, K, G, WAVES, 0, false, false, false, true>;
+            if (hl == 1) kern = fit_kernel<D, C, K, G, WAVES, 1, false, false, false, true>;
+            if (hl == 2) kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, false, false, true>;
+            nb = 1;
+        }
+    }
     const size_t shm = T::bytes(a.N, a.loss_w != nullptr, D - hl, false);
     FitArgs aa = a;
     size_t shm_all = shm;
@@ -2048,7 +2096,7 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
     if (e != hipSuccess) return e;
-    const int grid = (a.B + T::NB - 1) / T::NB;
+    const int grid = (a.B + nb - 1) / nb;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }

@@ -20,6 +20,8 @@ struct smoe_context {
     float* d_ssim_T;     // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
     double* d_partials;  // workspace of smoe_reduce_scalars
     int force_g;
+    int pair_occ;        // wavefronts per CU the 64-lane fit kernel reaches (-1: not asked yet)
+    int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
 };
@@ -144,6 +146,20 @@ int wanted_lanes(const smoe_context* h, int num_blocks) {
     return 64;
 }
 
+// One block on BOTH wavefronts of a workgroup (fit_kernel PAIR): when the batch leaves at most one wavefront per SIMD
+// (1 024 SIMDs) a second one is nearly free to the SIMD (profiles/r02/ubench_valu.txt: 5.6 -> 3.2 cycles per instruction),
+// provided the kernel's registers let two wavefronts share a SIMD.  Measured (scripts/pair_check.py): ONE 512x512 image
+// 86 -> 93 Gpx-it/s, 1 020 blocks of 16x16x4 RGB 92 -> 123; 1 536 blocks 124 -> 108 (no longer pays).
+constexpr int PAIR_MAX_BLOCKS = 1024;
+bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
+    if (v->G != 64 || v->W != 2 || h->N < 128) return false;
+    if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov) return false;
+    if (h->force_pair) return h->force_pair > 0;
+    if (num_blocks > PAIR_MAX_BLOCKS) return false;
+    if (h->pair_occ < 0) h->pair_occ = v->fit_waves_per_cu(h->N, false);     // wavefronts per CU of the 64-lane kernel
+    return h->pair_occ >= 8;
+}
+
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
@@ -241,6 +257,8 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->cfg = *cfg;
     h->N = (int)N;
     h->force_g = 0;
+    h->force_pair = 0;
+    h->pair_occ = -1;
     h->d_coords = nullptr;
     h->d_probes = nullptr;
     h->d_ssim_T = nullptr;
@@ -360,9 +378,12 @@ int smoe_get_coords(smoe_handle h, float* host_out) {
 
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_tiling: null handle");
-    if (lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64)
-        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32 or 64");
-    h->force_g = lanes_per_block;
+    if (lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64 && lanes_per_block != 128)
+        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32, 64 or 128");
+    // 128 = the 64-lane kernels with one block on both wavefronts of a workgroup (margin loss, quantization_mode 0 / 1,
+    // train_inverse_cov off; other graphs run the plain 64-lane kernel)
+    h->force_g = (lanes_per_block == 128) ? 64 : lanes_per_block;
+    h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0) ? 0 : -1);
     return SMOE_OK;
 }
 
@@ -432,6 +453,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.kc = h->kc;
     const int hoist = hoist_level(h, v);
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1]; a.bt = c.block_shape[2];
+    a.pair = wants_pair(h, v, num_blocks) ? 1 : 0;
     if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fit_ic(a, hoist, (hipStream_t)stream), "smoe_fit (inverse covariance) launch");

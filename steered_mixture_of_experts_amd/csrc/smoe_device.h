@@ -57,6 +57,7 @@ struct FitArgs {
     const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11], 3-d blocks: Tt [bt][11] (null otherwise)
     int bh, bw, bt;
     int desc_off;             // float offset of the owner-side gradient descriptors in the dynamic LDS (set by the launcher; 0 = off)
+    int pair;                 // few blocks: one block per 2-wavefront workgroup (64-lane tiling, margin loss; fit_kernel PAIR)
     KernelConsts kc;
 };
 

@@ -47,7 +47,15 @@ EXTRA_SHAPES = [
 ]
 ALL_SHAPES = [(s, 16) for s in SHAPES] + [(s, 64) for s in SHAPES] + [(s, 32) for s in SHAPES[:5]] \
     + [(s, 16) for s in EXTRA_SHAPES] + [(s, 64) for s in EXTRA_SHAPES]
-ALL_IDS = ["x".join(map(str, s[0])) + f"-c{s[1]}-k" + "x".join(map(str, s[2])) + f"-g{t}" for s, t in ALL_SHAPES]
+# 128 = one block on both wavefronts of a workgroup (smoe_fit only: the evaluation has no such mode)
+FIT_SHAPES = ALL_SHAPES + [(s, 128) for s in SHAPES] + [(s, 128) for s in EXTRA_SHAPES[::3]]
+
+
+def _ids(cases):
+    return ["x".join(map(str, s[0])) + f"-c{s[1]}-k" + "x".join(map(str, s[2])) + f"-g{t}" for s, t in cases]
+
+
+ALL_IDS = _ids(ALL_SHAPES)
 
 
 def _engine(shape, C, K, **kw):
@@ -163,7 +171,7 @@ def test_forward_parity(case, tiling):
     eng.close()
 
 
-@pytest.mark.parametrize("case,tiling", ALL_SHAPES, ids=ALL_IDS)
+@pytest.mark.parametrize("case,tiling", FIT_SHAPES, ids=_ids(FIT_SHAPES))
 def test_one_step_parity(case, tiling):
     """One train iteration: gradients enter Adam's first step as sign-like updates, so
     parity is checked on m (= 0.1*g, exposes the gradient itself), v and the parameters."""
@@ -363,7 +371,7 @@ def test_error_paths():
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [16, 64])
+@pytest.mark.parametrize("tiling", [16, 64, 128])
 def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     """The fit kernel's per-pixel loss-weight path (padding / loss masks, smoe.py:550,932), the l1
     regularisers (smoe.py:1027,1044) and gradient clipping (smoe.py:1152-1153) against the oracle."""
@@ -409,7 +417,7 @@ def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [16, 64])
+@pytest.mark.parametrize("tiling", [16, 64, 128])
 def test_only_y_gamma(tiling):
     """gamma_mask (smoe.py:725-729): slopes act and train only for channel 0."""
     shape, C, kpd = (16, 16), 3, [2, 2]
