@@ -246,21 +246,27 @@ def fq_apply(x, mn, mx, bits, T):
     return np.where(zero, T(0), q).astype(T), np.where(zero, True, inside)
 
 
-def _fq_minmax_vars(x, sel, bits, offset, T):
+def _fq_minmax_vars(x, sel, bits, offset, T, noshift=False):
     """Mode-3 tensor (smoe.py:497-530): range = min / max of x over the selected elements ``sel`` (bool, same
     shape as x) of each block.  ``offset``: the ``fake_quant(x - min, 0, max - min) + min`` form (A_diagonal,
     nu_e), else ``fake_quant(x, min, max)``.  Returns the q-tensor and the linear map of the backward pass
     as masks: g -> g*between + tie_lo * sum(g*below) + tie_hi * sum(g*above) -- fake_quant_with_min_max_vars
     sends what falls outside the NUDGED range to its min / max input, and reduce_min / reduce_max hand that
     to the extreme elements, split equally over ties.  (Nudging keeps 0 exactly representable: an all-positive
-    range [lo, hi] becomes [0, hi - lo], so e.g. centres above hi - lo are clamped -- restated as is.)"""
+    range [lo, hi] becomes [0, hi - lo], so e.g. centres above hi - lo are clamped -- restated as is.)
+    ``noshift`` (radial_as, smoe.py:498-504): ``fake_quant(x, 0, max - min) + min`` -- the input is NOT shifted by the
+    minimum (restated as is).  Backward: the range's lower end is the constant 0 (what falls below it is lost), its upper
+    end max - min hands sum(g*above) to the maximum and takes it from the minimum, and the added minimum collects
+    sum(g): the minimum receives sum(g * ~above)."""
     ax = tuple(range(1, x.ndim))
     lo = np.where(sel, x, np.inf).min(axis=ax, keepdims=True)
     hi = np.where(sel, x, -np.inf).max(axis=ax, keepdims=True)
     none = ~sel.any(axis=ax, keepdims=True)
     lo = np.where(none, 0, lo).astype(T)
     hi = np.where(none, 0, hi).astype(T)
-    if offset:
+    if noshift:
+        v, rmin, rmax, back = x, np.zeros_like(lo), hi - lo, lo
+    elif offset:
         v, rmin, rmax, back = x - lo, np.zeros_like(lo), hi - lo, lo
     else:
         v, rmin, rmax, back = x, lo, hi, np.zeros_like(lo)
@@ -276,7 +282,8 @@ def _fq_minmax_vars(x, sel, bits, offset, T):
     tie_hi = np.logical_and(sel, x == hi).astype(T)
     tie_lo = tie_lo / np.maximum(tie_lo.sum(axis=ax, keepdims=True), 1)
     tie_hi = tie_hi / np.maximum(tie_hi.sum(axis=ax, keepdims=True), 1)
-    return q, {"between": ~(below | above), "below": below, "above": above, "tie_lo": tie_lo, "tie_hi": tie_hi}
+    to_lo = ~above if noshift else below
+    return q, {"between": ~(below | above), "below": to_lo, "above": above, "tie_lo": tie_lo, "tie_hi": tie_hi}
 
 
 def quantize_graph_params(p, cfg: OracleConfig, T):
@@ -300,7 +307,9 @@ def quantize_graph_params(p, cfg: OracleConfig, T):
             return np.broadcast_to(keep.reshape(keep.shape + (1,) * (x.ndim - 2)), x.shape)
         d = q["A_diagonal"].shape[-1]
         diag_sel = np.logical_and(sel_all(q["A_diagonal"]), np.eye(d, dtype=bool))
-        q["A_diagonal"], back["A_diagonal"] = _fq_minmax_vars(q["A_diagonal"], diag_sel, bd[0], True, T)
+        # radial_as: the variable is ONE value per kernel (here tiled over the diagonal: sums and tie counts both come
+        # out d times the reference's, their quotients equal) and the reference does not shift it (smoe.py:498-504)
+        q["A_diagonal"], back["A_diagonal"] = _fq_minmax_vars(q["A_diagonal"], diag_sel, bd[0], True, T, noshift=cfg.radial_as)
         q["A_corr"], back["A_corr"] = _fq_minmax_vars(q["A_corr"], sel_all(q["A_corr"]), bd[0], False, T)
         if cfg.train_musx:
             q["musX"], back["musX"] = _fq_minmax_vars(q["musX"], sel_all(q["musX"]), bd[1], False, T)

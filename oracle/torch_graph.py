@@ -72,7 +72,7 @@ def _fake_quant_args(x, mn, mx, bits):
 
 
 def quantize_graph_params(params, *, quantization_mode, quantize_pis, bit_depths, lower_bounds, upper_bounds,
-                          train_musx=True):
+                          train_musx=True, radial_as=False):
     """smoe.py:474-538: the fake-quantised views of the variables the graph is built on.
     bit_depths / bounds order: A, musX, nu_e, pis, gamma_e (smoe_test.py:302-309)."""
     pis_v, musX_v = params["pis"], params["musX"]
@@ -90,9 +90,13 @@ def quantize_graph_params(params, *, quantization_mode, quantize_pis, bit_depths
         qnu = _fake_quant_args(nu_v, lb[2], ub[2], bd[2])
         qga = _fake_quant_args(gam_v, lb[4], ub[4], bd[4])
     elif quantization_mode == 3:
-        dg = torch.diagonal(Ad_v[pis_mask], dim1=-2, dim2=-1)
-        mn, mx = dg.min(), dg.max()
-        qAd = _FakeQuantVars.apply(Ad_v - mn, torch.zeros_like(mn), mx - mn, bd[0]) + mn
+        if radial_as:                     # smoe.py:498-504: the (K,) variable, NOT shifted by its minimum
+            mn, mx = Ad_v[pis_mask].min(), Ad_v[pis_mask].max()
+            qAd = _FakeQuantVars.apply(Ad_v, torch.zeros_like(mn), mx - mn, bd[0]) + mn
+        else:
+            dg = torch.diagonal(Ad_v[pis_mask], dim1=-2, dim2=-1)
+            mn, mx = dg.min(), dg.max()
+            qAd = _FakeQuantVars.apply(Ad_v - mn, torch.zeros_like(mn), mx - mn, bd[0]) + mn
         qAc = _FakeQuantVars.apply(Ac_v, Ac_v[pis_mask].min(), Ac_v[pis_mask].max(), bd[0])
         qmu = _FakeQuantVars.apply(musX_v, musX_v[pis_mask].min(), musX_v[pis_mask].max(), bd[1]) if train_musx else musX_v
         mn, mx = nu_v[pis_mask].min(), nu_v[pis_mask].max()
@@ -165,14 +169,16 @@ def tf_graph_block(params, coords, target, kernel_list, *, precision=8, margin=0
                    pis_l1=0.0, u_l1=0.0, start_pis=None, loss_w=None, ssim_opt=False, block_shape=None,
                    quantization_mode=0, quantize_pis=False, bit_depths=(20, 18, 6, 10, 10),
                    lower_bounds=(-2500, -.3, -5, 0, -32), upper_bounds=(2500, 1.3, 5, 2, 32), train_musx=True,
-                   train_inverse_cov=False, radial_as=False, kernel_count_as_norm_l1=False):
+                   train_inverse_cov=False, radial_as=False, kernel_count_as_norm_l1=False, musX_grid=None):
     """params: dict of torch tensors (K,), (K,d), (K,d,d), (K,d,d), (K,d,C), (K,C)
     with requires_grad; coords (N,d); target (N,C); kernel_list (K,) bool.
     Returns dict(loss, mse_op, res (N,C), w_e (Ka,N), indices)."""
     qp, pis_mask = quantize_graph_params(params, quantization_mode=quantization_mode, quantize_pis=quantize_pis,
                                          bit_depths=bit_depths, lower_bounds=lower_bounds, upper_bounds=upper_bounds,
-                                         train_musx=train_musx)
+                                         train_musx=train_musx, radial_as=radial_as)
     pis_v, musX_v = qp["pis"], qp["musX"]
+    if musX_grid is not None:                                                    # use_diff_center, smoe.py:390-394,746-747
+        musX_v = musX_v + musX_grid
     Ad_v, Ac_v = qp["A_diagonal"], qp["A_corr"]
     gam_v, nu_v = qp["gamma_e"], qp["nu_e"]
     K, d = musX_v.shape

@@ -222,7 +222,7 @@ struct BlockRanges {
 #pragma unroll
             for (int t = 0; t < 5; ++t) { lo[t] = 0.0f; hi[t] = 0.0f; }
         }
-        ad = fq_vars(lo[0], hi[0], kc.q_levels[0], true);
+        ad = fq_vars(lo[0], hi[0], kc.q_levels[0], true, kc.radial != 0);
         ac = fq_vars(lo[1], hi[1], kc.q_levels[0], false);
         mu = fq_vars(lo[2], hi[2], kc.q_levels[1], false);
         nu = fq_vars(lo[3], hi[3], kc.q_levels[2], true);
@@ -1299,7 +1299,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     if (lo == INF) { lo = 0.0f; hi = 0.0f; }                       // no kernel left
                     if (t == 1) { lo = fminf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }    // structural zeros of the A_corr variable
                     const float lv = (t < 2) ? a.kc.q_levels[0] : ((t == 2) ? a.kc.q_levels[1] : ((t == 3) ? a.kc.q_levels[2] : a.kc.q_levels[4]));
-                    const FqRange r = fq_vars(lo, hi, lv, t == 0 || t == 3);
+                    const FqRange r = fq_vars(lo, hi, lv, t == 0 || t == 3, t == 0 && a.kc.radial != 0);
                     if (sub < 5) {
                         float* o = s_rng + t * 8;
                         o[0] = r.nmin; o[1] = r.nmax; o[2] = r.scale; o[3] = r.inv;
@@ -1339,6 +1339,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                         const float* o = s_rng + qt[s] * 8;
                         FqRange r;
                         r.nmin = o[0]; r.nmax = o[1]; r.scale = o[2]; r.inv = o[3]; r.back = o[4]; r.zero = o[5] != 0.0f;
+                        r.shift = (qt[s] == 0 && a.kc.radial) ? 0.0f : r.back;       // radial_as: unshifted input (fq_vars)
                         q = fq_val(x, r);
                     }
                 }
@@ -1591,7 +1592,8 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     bel[s] = abv[s] = tlo[s] = thi[s] = false;
                     if (j < Lt::NPAR && qt[s] >= 0) {
                         const float* o = s_rng + qt[s] * 8;
-                        const float x = s_par[j], v = x - o[4];
+                        const bool unshifted = qt[s] == 0 && kc.radial;       // radial_as steering (fq_vars, noshift)
+                        const float x = s_par[j], v = unshifted ? x : x - o[4];
                         const bool zero = o[5] != 0.0f;
                         const bool keep = fq_val(s_par[(meta[s] >> 4) * Lt::PK + Lt::O_PI], rp) > 0.0f;
                         bel[s] = !zero && (v < o[0]);
@@ -1601,7 +1603,9 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
 #pragma unroll
                         for (int t = 0; t < 5; ++t) {
                             const bool hit = qt[s] == t;
-                            rs[t] += (hit && bel[s]) ? gq[s] : 0.0f;
+                            // unshifted: the lower end of the range is the constant 0 (below it: lost), and the added minimum
+                            // collects sum(g) while max - min takes sum(g * above) off it: the minimum receives sum(g * !above)
+                            rs[t] += (hit && (unshifted ? !abv[s] : bel[s])) ? gq[s] : 0.0f;
                             rs[5 + t] += (hit && abv[s]) ? gq[s] : 0.0f;
                             cn[t] += (hit && tlo[s]) ? 1.0f : 0.0f;
                             cn[5 + t] += (hit && thi[s]) ? 1.0f : 0.0f;

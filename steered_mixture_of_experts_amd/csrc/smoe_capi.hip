@@ -230,8 +230,6 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
                                            cfg->upper_bounds, &qmsg);
         if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_create: ") + qmsg);
     }
-    if (cfg->radial_as && cfg->quantization_mode == 3)
-        return fail(SMOE_ERR_UNSUPPORTED, "smoe_create: radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built");
     if (cfg->ssim_opt) {
         // the reference pads every axis SYMMETRIC by 5 (smoe.py:993-1003), which TF only accepts for axes of
         // at least 5 samples; 3-d blocks take the 11x11x11 window (smoe.py:999-1003, custom_ssim ndim=3)
@@ -597,8 +595,6 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
                                            cfg->upper_bounds, &qmsg);
         if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_shared_create: ") + qmsg);
     }
-    if (cfg->radial_as && cfg->quantization_mode == 3)
-        return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built");
     if (cfg->ssim_opt) {
         if (cfg->dim != 2) return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt is built for 2-d batches only");
         if (cfg->batch_shape[0] < 5 || cfg->batch_shape[1] < 5)

@@ -94,6 +94,7 @@ __device__ __forceinline__ float fqt(float x, const KernelConsts& kc, const floa
         const float* o = rng + t * 8;
         FqRange r;
         r.nmin = o[0]; r.nmax = o[1]; r.scale = o[2]; r.inv = o[3]; r.back = o[4]; r.zero = o[5] != 0.0f;
+        r.shift = (t == 0 && kc.radial) ? 0.0f : r.back;         // radial_as: unshifted input (fq_vars, smoe.py:498-504)
         return fq_val(x, r);
     }
     return fqv(x, kc, (t <= 1) ? 0 : ((t == 2) ? 1 : ((t == 3) ? 2 : 4)));
@@ -782,7 +783,7 @@ __device__ __forceinline__ void ranges_of_image(const smoe_params& p, int K, con
         if (lo == INF) { lo = 0.0f; hi = 0.0f; }                       // no kernel left
         if (t == 1) { lo = fminf(lo, 0.0f); hi = fmaxf(hi, 0.0f); }    // diagonal / upper entries of the A_corr variable (zero)
         const float lv = (t < 2) ? kc.q_levels[0] : ((t == 2) ? kc.q_levels[1] : ((t == 3) ? kc.q_levels[2] : kc.q_levels[4]));
-        const FqRange r = fq_vars(lo, hi, lv, t == 0 || t == 3);
+        const FqRange r = fq_vars(lo, hi, lv, t == 0 || t == 3, t == 0 && kc.radial != 0);
         float* o = qrng + t * 8;
         o[0] = r.nmin; o[1] = r.nmax; o[2] = r.scale; o[3] = r.inv;
         o[4] = r.back; o[5] = r.zero ? 1.0f : 0.0f; o[6] = lo; o[7] = hi;
@@ -828,12 +829,13 @@ __global__ void __launch_bounds__(RG_THREADS) shared_adam_routed_kernel(SharedAd
         const bool keep = S.pi > 0.0f;
         visit(S, [&](int t, float x, float& g) {
             const float* o = a.qrng + t * 8;
-            const float v = x - o[4];
+            const bool unshifted = t == 0 && a.kc.radial;        // radial_as steering: see fq_vars / the block kernels
+            const float v = unshifted ? x : x - o[4];
             const bool zero = o[5] != 0.0f;
 #pragma unroll
             for (int tt = 0; tt < 5; ++tt) {
                 const bool hit = tt == t;
-                st[tt] += (hit && !zero && v < o[0]) ? g : 0.0f;
+                st[tt] += (hit && (unshifted ? !(!zero && v > o[1]) : (!zero && v < o[0]))) ? g : 0.0f;
                 st[5 + tt] += (hit && !zero && v > o[1]) ? g : 0.0f;
                 st[10 + tt] += (hit && keep && x == o[6]) ? 1.0f : 0.0f;
                 st[15 + tt] += (hit && keep && x == o[7]) ? 1.0f : 0.0f;
@@ -848,7 +850,7 @@ __global__ void __launch_bounds__(RG_THREADS) shared_adam_routed_kernel(SharedAd
         S.g_pi = fq_pass(S.pi_raw, a.kc, 3) ? S.g_pi : 0.0f;
         visit(S, [&](int t, float x, float& g) {
             const float* o = a.qrng + t * 8;
-            const float v = x - o[4];
+            const float v = (t == 0 && a.kc.radial) ? x : x - o[4];
             const bool zero = o[5] != 0.0f;
             float r = (!zero && (v < o[0] || v > o[1])) ? 0.0f : g;
             r += (keep && x == o[6]) ? s_tot[t] / fmaxf(s_tot[10 + t], 1.0f) : 0.0f;

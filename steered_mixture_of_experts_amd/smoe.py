@@ -111,8 +111,6 @@ class Smoe:
         if quantization_mode >= 2 and use_diff_center:
             raise NotImplementedError("fake-quantised centre OFFSETS (use_diff_center with quantization_mode 2/3) "
                                       "are not built: the engine works on absolute centres")
-        if radial_as and quantization_mode == 3:
-            raise NotImplementedError("radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built")
         if add_kernel_slots:
             raise NotImplementedError("progressive kernel adding changes K over time; not part of the hot path")
         if overlap_of_batches:
@@ -713,8 +711,6 @@ class SharedSmoe:
         self.lower_bounds = [-2500, -.3, -5, 0, -32] if lower_bounds is None else list(lower_bounds)
         self.upper_bounds = [2500, 1.3, 5, 2, 32] if upper_bounds is None else list(upper_bounds)
         self.radial_as = bool(radial_as)                                   # smoe.py:429-434,714-719
-        if self.radial_as and quantization_mode == 3:
-            raise NotImplementedError("radial_as with quantization_mode 3 (its own range formula, smoe.py:498-504) is not built")
         self.train_inverse_cov = bool(train_inverse_cov)                  # smoe.py:41: the constructor default is True
         self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
         if self.ssim_opt and image.ndim - 1 != 2:

@@ -108,7 +108,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
-    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}, {"radial_as": True, "quantization_mode": 3},
+    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True},
                {"quantization_mode": 3, "use_diff_center": True}):
         with pytest.raises(NotImplementedError):
             Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
@@ -508,10 +508,11 @@ def test_radial_steering_through_the_facade(ic):
     assert np.array_equal(r.get_reconstruction(), s.get_reconstruction())
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_radial_steering_with_a_quantisation_mode(mode):
-    """radial_as with quantization_mode 1 (quantise the (K,) variable at validation, quantizer.py radial paths) and 2
-    (fixed-range fake quant inside the graph): the fit follows oracle.fit, the quantised evaluation runs."""
+    """radial_as with quantization_mode 1 (quantise the (K,) variable at validation, quantizer.py radial paths), 2
+    (fixed-range fake quant inside the graph) and 3 (range from the data, smoe.py:498-504): the fit follows oracle.fit,
+    the quantised evaluation runs."""
     img = _image(32, 32, seed=14)
     kw = dict(quantization_mode=mode, quantize_pis=True, bit_depths=[14, 12, 8, 10, 10], lower_bounds=[-60, -.3, -1, 0, -4],
               upper_bounds=[60, 1.3, 2, 2, 4])

@@ -177,8 +177,5 @@ def test_quant_configuration_errors():
     with pytest.raises(_lib.SmoeError) as e:
         BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantization_mode=5))
     assert e.value.code == _lib.SMOE_ERR_INVALID
-    with pytest.raises(_lib.SmoeError) as e:
-        BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantization_mode=3, radial_as=True))
-    assert e.value.code == _lib.SMOE_ERR_UNSUPPORTED
     with pytest.raises(_lib.SmoeError):
         BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantize_pis=True, bit_depths=(20, 18, 6, 30, 10)))

@@ -539,6 +539,39 @@ def test_shared_radial_steering_with_fixed_range_quantisation():
     eng.close()
 
 
+def test_shared_radial_steering_with_ranges_from_the_data():
+    """radial_as together with quantization_mode 3 in the shared-kernel mode (smoe.py:498-504, unshifted input)."""
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    kw = dict(pis_l1=0.05, u_l1=0.002, radial_as=True, quantization_mode=3, quantize_pis=True, bit_depths=(12, 10, 6, 10, 8))
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False, perturb=True, **kw)
+    a0 = np.abs(p["A_diagonal"][0, :, 0, 0])
+    a0[3] = a0.min()                                   # two tied minima
+    a0[7] = a0.min()
+    p["A_diagonal"] = (a0[None, :, None, None] * np.eye(2)).astype(np.float32)
+    p["A_corr"] = np.zeros_like(p["A_corr"])
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, False, **kw)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    recon = eng.forward(T, dp, dl, want_recon=True, update_lists=False)["recon"].cpu().numpy().transpose(0, 2, 1)
+    # identical parameters in every batch: the (linear) fake-quant backward of the sum is the sum of the routed gradients
+    f32 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float32, want_grads=True, q_override=recon)
+    g32 = {k: v.sum(axis=0) for k, v in f32["grads"].items()}
+    st = eng.new_adam_state(dp)
+    eng.accumulate(T, dp, dl)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    m = {k: v.cpu().numpy() for k, v in st.m.items()}
+    for name in ("A_diagonal", "musX", "nu_e", "pis"):
+        scale = np.abs(g32[name]).max() + 1e-30
+        assert np.abs(m[name] / 0.1 - g32[name]).max() / scale < 1e-4, name
+    assert not m["A_corr"].any()
+    dg = np.diagonal(dp["A_diagonal"].cpu().numpy(), axis1=-2, axis2=-1)
+    assert np.all(dg[:, 0] == dg[:, 1])
+    eng.close()
+
+
 def test_gradient_buffer_goes_through_an_rccl_all_reduce():
     """Multi-GPU shared mode: the accumulated fp64 gradient buffer (library memory wrapped as a torch tensor) is what
     torch.distributed all-reduces between smoe_shared_accumulate and smoe_shared_apply.  One rank is all this box has:
