@@ -185,6 +185,13 @@ const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks);
 /* Resident wavefronts per CU the runtime grants smoe_fit's kernel for num_blocks (diagnostics). */
 int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks);
 
+/* use_diff_center (smoe.py:390-394,746-747: the trained variable is the OFFSET from the kernel grid, the graph reads
+ * fake_quant(offset) + grid).  The engines keep grid + offset in musX; with quantization_mode 2 / 3 they need the grid to
+ * quantise the offsets: caller-owned device array [num_blocks, K, d] laid out like musX and indexed like the musX of every
+ * later smoe_forward / smoe_fit / smoe_update_kernel_list call; it must stay alive until cleared with NULL or the handle
+ * is destroyed.  Without quantization_mode 2 / 3 it is not read. */
+int smoe_set_center_grid(smoe_handle h, const float* grid);
+
 /* Force the lanes-per-block tiling (16, 32, 64; 0 = automatic).  128 = the 64-lane kernels with ONE block on both
  * wavefronts of a workgroup in smoe_fit (the automatic choice for at most 1 024 blocks of the plain margin-loss graph;
  * other graphs and the evaluation run the plain 64-lane kernel).  Tuning / test hook. */
@@ -235,6 +242,8 @@ int smoe_shared_destroy(smoe_shared_handle h);
  * batch index by every later forward / accumulate / fit call; it must stay alive until cleared with NULL or the
  * handle is destroyed.  Ignored with ssim_opt, as in the reference. */
 int smoe_shared_set_loss_weights(smoe_shared_handle h, const float* loss_w);
+/* use_diff_center in the shared-kernel mode: the kernel-grid centres [K, d] (see smoe_set_center_grid). */
+int smoe_shared_set_center_grid(smoe_shared_handle h, const float* grid);
 int smoe_shared_num_batches(smoe_shared_handle h);
 int smoe_shared_list_words(smoe_shared_handle h);
 

@@ -78,6 +78,9 @@ class OracleConfig:
     kernel_count_as_norm_l1: bool = False  # smoe.py:1022-1027: the pis l1 term is normalised by count(qpis > 0), not start_pis
     radial_as: bool = False               # smoe.py:349-365,429-434,714-719: ONE steering value per kernel (A = a I),
                                           # A_corr not trainable.  Held here as A_diagonal with equal diagonal entries
+    mus_grid: Optional[np.ndarray] = None  # use_diff_center (smoe.py:390-394,746-747): the kernel-grid centres (B,K,d) the
+                                          # trained OFFSETS are relative to.  ``musX`` holds grid + offset everywhere (the
+                                          # engines' convention); only the fake quantisation needs the offsets themselves
     quantization_mode: int = 0            # 0/1: none in the graph; 2: fixed ranges; 3: min/max of the model's kernels
     quantize_pis: bool = False            # smoe.py:474 (the reference CLI passes True by default, smoe_test.py:304)
     bit_depths: Tuple[int, ...] = (20, 18, 6, 10, 10)                 # smoe_test.py:302
@@ -298,6 +301,10 @@ def quantize_graph_params(p, cfg: OracleConfig, T):
         q["pis"], inside = fq_apply(q["pis"], T(lb[3]), T(ub[3]), bd[3], T)
         back["pis"] = {"between": inside}
     keep = q["pis"] > 0
+    grid = None
+    if mode >= 2 and cfg.mus_grid is not None:              # smoe.py:746-747: musX = qmusX + musX_grid, qmusX = fq(offset)
+        grid = np.broadcast_to(np.asarray(cfg.mus_grid).astype(T), q["musX"].shape)
+        q["musX"] = q["musX"] - grid
     if mode == 2:
         for name, i in (("A_diagonal", 0), ("A_corr", 0), ("musX", 1), ("nu_e", 2), ("gamma_e", 4)):
             q[name], inside = fq_apply(q[name], T(lb[i]), T(ub[i]), bd[i], T)
@@ -315,6 +322,8 @@ def quantize_graph_params(p, cfg: OracleConfig, T):
             q["musX"], back["musX"] = _fq_minmax_vars(q["musX"], sel_all(q["musX"]), bd[1], False, T)
         q["nu_e"], back["nu_e"] = _fq_minmax_vars(q["nu_e"], sel_all(q["nu_e"]), bd[2], True, T)
         q["gamma_e"], back["gamma_e"] = _fq_minmax_vars(q["gamma_e"], sel_all(q["gamma_e"]), bd[4], False, T)
+    if grid is not None:
+        q["musX"] = (q["musX"] + grid).astype(T)
     return q, back, keep
 
 

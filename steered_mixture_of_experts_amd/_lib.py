@@ -26,6 +26,7 @@ EXPORTS = (
     "smoe_shared_create", "smoe_shared_destroy", "smoe_shared_num_batches", "smoe_shared_list_words",
     "smoe_shared_forward", "smoe_shared_accumulate", "smoe_shared_apply", "smoe_shared_grad_buffer",
     "smoe_shared_fit", "smoe_shared_update_kernel_list", "smoe_shared_set_loss_weights",
+    "smoe_set_center_grid", "smoe_shared_set_center_grid",
 )
 
 
@@ -116,6 +117,8 @@ def load() -> C.CDLL:
     lib.smoe_shared_fit.argtypes = [vp, fp, C.POINTER(SmoeParams), C.POINTER(SmoeAdamState), i32, fp, fp, fp, vp]
     lib.smoe_shared_update_kernel_list.argtypes = [vp, i32, i32, C.POINTER(SmoeParams), fp, vp]
     lib.smoe_shared_set_loss_weights.argtypes = [vp, fp]
+    lib.smoe_set_center_grid.argtypes = [vp, fp]
+    lib.smoe_shared_set_center_grid.argtypes = [vp, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("smoe_fit_variant", "smoe_last_error"):

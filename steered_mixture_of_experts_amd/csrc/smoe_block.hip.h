@@ -245,8 +245,10 @@ __device__ __forceinline__ float count_pis(const float* P) {
 // FULL = false: only the pis (quantize_pis, the reference CLI default) -- a few instructions, kept as a
 // run-time branch in the default kernels; modes 2 / 3 live in their own instantiations (QUANT) so that their
 // register footprint does not reach the hot kernels.
+// G (use_diff_center, smoe.py:390-394,746-747): the block's kernel-grid centres [K][D] or null -- the quantised variable is
+// the OFFSET musX - grid, the graph reads fake_quant(offset) + grid.
 template <int D, int C, int K, bool FULL>
-__device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc) {
+__device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc, const float* __restrict__ G = nullptr) {
     using Lt = Layout<D, C, K>;
     if (kc.qpis) {
         const FqRange r = fq_fixed(kc, 3);
@@ -254,6 +256,14 @@ __device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc
         for (int k = 0; k < K; ++k) P[k * Lt::PK + Lt::O_PI] = fq_val(P[k * Lt::PK + Lt::O_PI], r);
     }
     if constexpr (!FULL) return;
+    float gr[K * D];
+    const bool centred = (G != nullptr) && (kc.qmode >= 2);
+    if (centred) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int l = 0; l < D; ++l) { gr[k * D + l] = G[k * D + l]; P[k * Lt::PK + Lt::O_MU + l] -= gr[k * D + l]; }
+    }
     if (kc.qmode == 2) {
         const FqRange ra = fq_fixed(kc, 0), rm = fq_fixed(kc, 1), rn = fq_fixed(kc, 2), rg = fq_fixed(kc, 4);
 #pragma unroll
@@ -289,6 +299,12 @@ __device__ __forceinline__ void quantize_packed(float* P, const KernelConsts& kc
 #pragma unroll
             for (int i = 0; i < D * C; ++i) p[Lt::O_GA + i] = fq_val(p[Lt::O_GA + i], br.ga);
         }
+    }
+    if (centred) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int l = 0; l < D; ++l) P[k * Lt::PK + Lt::O_MU + l] += gr[k * D + l];
     }
 }
 
@@ -1206,12 +1222,14 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     // wave per SIMD over them); quantize_pis alone needs just the uniform constants of the pis range.
     constexpr int QS = QUANT ? T::SPL : 1;
     float lr[T::SPL], reg[T::SPL], qlo[QS], qhi[QS], qsc[QS], qiv[QS];
+    float goff[QS];          // use_diff_center: the kernel-grid centre of a musX slot (the quantised variable is musX - grid), else 0
     int meta[T::SPL], qt[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
         qlo[s] = -__builtin_huge_valf(); qhi[s] = __builtin_huge_valf();
         qsc[s] = qiv[s] = 0.0f;
         qt[s] = -1;
+        goff[s] = 0.0f;
     }
 #pragma unroll
     for (int s = 0; s < T::SPL; ++s) {
@@ -1241,6 +1259,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             const int qg = (tensor == 0) ? 3 : ((tensor == 1) ? 1 : ((tensor == 4) ? 4 : ((tensor == 5) ? 2 : 0)));
             meta[s] = tensor | (kern << 4);
             if constexpr (QUANT) {
+                if (tensor == 1 && a.mus_grid != nullptr && a.kc.qmode >= 2) goff[s] = a.mus_grid[off];
                 if ((tensor == 0 && a.kc.qpis) || (tensor != 0 && a.kc.qmode == 2)) {
                     qlo[s] = a.kc.q_nmin[qg]; qhi[s] = a.kc.q_nmax[qg]; qsc[s] = a.kc.q_scale[qg]; qiv[s] = a.kc.q_inv[qg];
                 }
@@ -1283,7 +1302,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     const int j = T::slot_of(sub, s);
                     if (j < Lt::NPAR && qt[s] >= 0) {
                         const bool keep = fq_val(s_par[(meta[s] >> 4) * Lt::PK + Lt::O_PI], rp) > 0.0f;      // pis_mask = qpis > 0
-                        const float x = s_par[j];
+                        const float x = s_par[j] - goff[s];
 #pragma unroll
                         for (int t = 0; t < 5; ++t) {
                             const bool hit = keep && (qt[s] == t);
@@ -1328,7 +1347,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
         for (int s = 0; s < T::SPL; ++s) {
             const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
-                const float x = s_par[j];
+                const float x = s_par[j] - goff[s];
                 float q = x;
                 if (qsc[s] != 0.0f) {                       // fixed range (pis; mode 2)
                     const float cl = fminf(fmaxf(x, qlo[s]), qhi[s]);
@@ -1343,7 +1362,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                         q = fq_val(x, r);
                     }
                 }
-                s_q[j] = q;
+                s_q[j] = q + goff[s];
             } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
                 s_q[Lt::LP_ACT + (j - Lt::S_CNT)] = s_par[Lt::LP_ACT + (j - Lt::S_CNT)];
             } else if (j == Lt::S_LOSS) {
@@ -1593,7 +1612,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
                     if (j < Lt::NPAR && qt[s] >= 0) {
                         const float* o = s_rng + qt[s] * 8;
                         const bool unshifted = qt[s] == 0 && kc.radial;       // radial_as steering (fq_vars, noshift)
-                        const float x = s_par[j], v = unshifted ? x : x - o[4];
+                        const float x = s_par[j] - goff[s], v = unshifted ? x : x - o[4];
                         const bool zero = o[5] != 0.0f;
                         const bool keep = fq_val(s_par[(meta[s] >> 4) * Lt::PK + Lt::O_PI], rp) > 0.0f;
                         bel[s] = !zero && (v < o[0]);
@@ -1637,7 +1656,7 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
             float gsum = gq[s];
             // fixed-range fake quant: straight-through inside the nudged range only
             if constexpr (QUANT) {
-                gsum = (pv >= qlo[s] && pv <= qhi[s]) ? gsum : 0.0f;
+                gsum = (pv - goff[s] >= qlo[s] && pv - goff[s] <= qhi[s]) ? gsum : 0.0f;
             } else {
                 if (patch_pis && meta[s] >= 0 && (meta[s] & 15) == 0) gsum = (pv >= kc.q_nmin[3] && pv <= kc.q_nmax[3]) ? gsum : 0.0f;
             }
@@ -1795,7 +1814,8 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
 
     BlockRegs<D, C, K> R;
     R.load(s_par);
-    if (a.kc.qmode != 0 || a.kc.qpis != 0) quantize_packed<D, C, K, QUANT>(R.P, a.kc);
+    if (a.kc.qmode != 0 || a.kc.qpis != 0)
+        quantize_packed<D, C, K, QUANT>(R.P, a.kc, (QUANT && a.mus_grid != nullptr) ? a.mus_grid + (size_t)b * (K * D) : nullptr);
     R.template derive<IC>(a.kc);
     float xc[D];                                   // coordinates of the lane's first pixel (hoisted axes: of all its pixels)
 #pragma unroll
@@ -2028,7 +2048,7 @@ __global__ void readmit_quant_kernel(ReadmitArgs a, KernelConsts kc) {
         decode_slot<D, C, K>(j, b, tensor, off, kern);
         P[j] = pick(a.p, tensor)[off];
     }
-    quantize_packed<D, C, K, true>(P, kc);
+    quantize_packed<D, C, K, true>(P, kc, (a.mus_grid != nullptr) ? a.mus_grid + (size_t)b * (K * D) : nullptr);
     int nprobe = 1;
 #pragma unroll
     for (int l = 0; l < D; ++l) nprobe *= 3;

@@ -20,6 +20,7 @@ struct smoe_context {
     float* d_ssim_T;     // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
     double* d_partials;  // workspace of smoe_reduce_scalars
     int force_g;
+    const float* mus_grid;   // use_diff_center: kernel-grid centres [B,K,D] of the blocks the calls pass (smoe_set_center_grid), or null
     int pair_occ;        // wavefronts per CU the 64-lane fit kernel reaches (-1: not asked yet)
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     smoe::KernelConsts kc;
@@ -257,6 +258,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->force_g = 0;
     h->force_pair = 0;
     h->pair_occ = -1;
+    h->mus_grid = nullptr;
     h->d_coords = nullptr;
     h->d_probes = nullptr;
     h->d_ssim_T = nullptr;
@@ -374,6 +376,12 @@ int smoe_get_coords(smoe_handle h, float* host_out) {
     return SMOE_OK;
 }
 
+int smoe_set_center_grid(smoe_handle h, const float* grid) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_center_grid: null handle");
+    h->mus_grid = grid;
+    return SMOE_OK;
+}
+
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_tiling: null handle");
     if (lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64 && lanes_per_block != 128)
@@ -418,6 +426,7 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.reg_u = h->cfg.u_l1;
     a.kc = h->kc;
     a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1]; a.bt = h->cfg.block_shape[2];
+    a.mus_grid = h->mus_grid;
     if (h->cfg.ssim_opt) HIP_TRY(v->fwd_ssim(a, (hipStream_t)stream), "smoe_forward (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fwd_quant(a, (hipStream_t)stream), "smoe_forward (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fwd_ic(a, (hipStream_t)stream), "smoe_forward (inverse covariance) launch");
@@ -452,6 +461,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     const int hoist = hoist_level(h, v);
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1]; a.bt = c.block_shape[2];
     a.pair = wants_pair(h, v, num_blocks) ? 1 : 0;
+    a.mus_grid = h->mus_grid;
     if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fit_ic(a, hoist, (hipStream_t)stream), "smoe_fit (inverse covariance) launch");
@@ -475,6 +485,7 @@ int smoe_update_kernel_list(smoe_handle h, int32_t num_blocks, const smoe_params
     smoe::ReadmitArgs a;
     a.p = *p; a.active = active; a.probes = h->d_probes; a.B = num_blocks; a.K = h->cfg.kernels;
     a.inverse_cov = h->kc.inverse_cov;
+    a.mus_grid = h->mus_grid;
     if (h->kc.qmode || h->kc.qpis) {                 // the probe test runs on the fake-quantised variables
         const smoe::Variant* v = find_variant(h, num_blocks, false);
         if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_update_kernel_list: no kernel variant");
@@ -528,6 +539,7 @@ struct smoe_shared_context {
     float* d_qrng;        // SharedRangesArgs records (mode-3 ranges, count of qpis > 0)
     bool need_ranges;     // quantization_mode 3 or kernel_count_as_norm_l1
     const float* loss_w;  // caller-owned [NB][Nb] loss weights (smoe_shared_set_loss_weights) or null
+    const float* mus_grid;   // caller-owned kernel-grid centres [K][D] (smoe_shared_set_center_grid) or null
     smoe::KernelConsts kc;
 };
 
@@ -554,13 +566,14 @@ void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
     a.racc = h->d_racc;
     a.nact = h->d_racc + (size_t)c.kernels * h->PK;
     a.qrng = h->d_qrng;
+    a.mus_grid = h->mus_grid;
 }
 
 // the image-wide records follow the parameters of THIS call (the C ABI is stateless in the parameters)
 hipError_t refresh_ranges(const smoe_shared_context* h, const smoe_params* p, hipStream_t st) {
     if (!h->need_ranges) return hipSuccess;
     smoe::SharedRangesArgs r;
-    r.p = *p; r.qrng = h->d_qrng; r.K = h->cfg.kernels; r.kc = h->kc;
+    r.p = *p; r.qrng = h->d_qrng; r.K = h->cfg.kernels; r.kc = h->kc; r.mus_grid = h->mus_grid;
     return smoe::launch_shared_ranges(r, h->cfg.dim, h->cfg.channels, st);
 }
 
@@ -653,7 +666,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         }
     }
     const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
-    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->d_qrng = nullptr; h->loss_w = nullptr;
+    h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->d_qrng = nullptr; h->loss_w = nullptr; h->mus_grid = nullptr;
     h->need_ranges = cfg->quantization_mode == 3 || cfg->kernel_count_as_norm_l1 != 0;
     if (cfg->ssim_opt) {
         const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
@@ -733,6 +746,12 @@ int smoe_shared_destroy(smoe_shared_handle h) {
     return SMOE_OK;
 }
 
+int smoe_shared_set_center_grid(smoe_shared_handle h, const float* grid) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_set_center_grid: null handle");
+    h->mus_grid = grid;
+    return SMOE_OK;
+}
+
 int smoe_shared_set_loss_weights(smoe_shared_handle h, const float* loss_w) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_set_loss_weights: null handle");
     h->loss_w = loss_w;
@@ -800,6 +819,7 @@ int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, 
     a.reg_pi = c.pis_l1 / (float)(c.start_pis > 0 ? c.start_pis : c.kernels);
     a.reg_u = c.u_l1;
     a.qrng = h->d_qrng;
+    a.mus_grid = h->mus_grid;
     HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_apply ranges");
     HIP_TRY(smoe::launch_shared_adam(a, c.dim, c.channels, (hipStream_t)stream), "smoe_shared_apply launch");
     s->beta1_power *= c.beta1;
@@ -831,7 +851,7 @@ int smoe_shared_update_kernel_list(smoe_shared_handle h, int32_t first_batch, in
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::SharedReadmitArgs a;
     a.p = *p; a.lists = lists; a.probes = h->d_probes + (size_t)first_batch * h->cfg.dim * 3;
-    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW; a.kc = h->kc; a.qrng = h->d_qrng;
+    a.NB = num_batches; a.K = h->cfg.kernels; a.KW = h->KW; a.kc = h->kc; a.qrng = h->d_qrng; a.mus_grid = h->mus_grid;
     HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_update_kernel_list ranges");
     HIP_TRY(smoe::launch_shared_readmit(a, h->cfg.dim, (hipStream_t)stream), "smoe_shared_update_kernel_list launch");
     return SMOE_OK;

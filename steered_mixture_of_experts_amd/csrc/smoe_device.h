@@ -57,6 +57,7 @@ struct FitArgs {
     const float* ssim_T;      // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11], 3-d blocks: Tt [bt][11] (null otherwise)
     int bh, bw, bt;
     int desc_off;             // float offset of the owner-side gradient descriptors in the dynamic LDS (set by the launcher; 0 = off)
+    const float* mus_grid;    // use_diff_center with quantization_mode 2 / 3: kernel-grid centres [B,K,D] (null otherwise)
     int pair;                 // few blocks: one block per 2-wavefront workgroup (64-lane tiling, margin loss; fit_kernel PAIR)
     KernelConsts kc;
 };
@@ -74,6 +75,7 @@ struct FwdArgs {
     const float* coords;
     int B, N, update_active;
     int hoist;                // trailing axes whose coordinate is a lane constant (same rule as smoe_fit)
+    const float* mus_grid;    // as in FitArgs
     int regt;                 // evaluation kernel: targets in registers, no staged planes in LDS (set by the launcher)
     float reg_pi, reg_u;
     const float* ssim_T;
@@ -87,6 +89,7 @@ struct ReadmitArgs {
     const float* probes;      // [D][3] = {min, max, mid} per axis
     int B, K;
     int inverse_cov;          // train_inverse_cov: maha = r^T A r
+    const float* mus_grid;    // as in FitArgs
 };
 
 struct BestArgs {
@@ -148,6 +151,7 @@ struct SharedArgs {
     int ssim;                 // 1: loss_pixel = 1 - SSIM of the batch
     int ssim_off;             // float offset of the SSIM planes inside the workgroup's LDS
     const float* qrng;        // image-wide records of shared_ranges_kernel (mode 3 ranges, count of qpis > 0); see SharedRangesArgs
+    const float* mus_grid;    // use_diff_center with quantization_mode 2 / 3: kernel-grid centres [K][D] (null otherwise)
 };
 
 struct SharedAdamArgs {
@@ -161,6 +165,7 @@ struct SharedAdamArgs {
     float reg_pi, reg_u;
     KernelConsts kc;          // fake quant of the variables (quantize_pis, quantization_mode 2 / 3)
     float* qrng;              // records of shared_ranges_kernel for the CURRENT parameters (mode 3, kernel_count_as_norm_l1)
+    const float* mus_grid;    // as in SharedArgs
 };
 
 struct SharedReadmitArgs {
@@ -170,6 +175,7 @@ struct SharedReadmitArgs {
     int NB, K, KW;
     KernelConsts kc;
     const float* qrng;
+    const float* mus_grid;    // as in SharedArgs
 };
 
 // Image-wide quantities of the fake-quantised graph, recomputed from the parameters before every launch that reads them:
@@ -182,6 +188,7 @@ struct SharedRangesArgs {
     float* qrng;
     int K;
     KernelConsts kc;
+    const float* mus_grid;    // as in SharedArgs
 };
 
 size_t shared_lds_bytes(int D, int C, int K, int KW);

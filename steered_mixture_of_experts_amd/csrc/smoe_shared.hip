@@ -99,6 +99,19 @@ __device__ __forceinline__ float fqt(float x, const KernelConsts& kc, const floa
     }
     return fqv(x, kc, (t <= 1) ? 0 : ((t == 2) ? 1 : ((t == 3) ? 2 : 4)));
 }
+// Centre l of kernel k as the graph reads it.  use_diff_center with quantization_mode 2 / 3 (G = the kernel-grid centres
+// [K][D], smoe.py:390-394,746-747): the quantised variable is the OFFSET musX - grid, the graph reads fq(offset) + grid.
+template <int D>
+__device__ __forceinline__ float mu_off(const float* __restrict__ musX, const float* __restrict__ G, const KernelConsts& kc, int k, int l) {
+    const float x = musX[(size_t)k * D + l];
+    return (G != nullptr && kc.qmode >= 2) ? x - G[(size_t)k * D + l] : x;
+}
+template <int D>
+__device__ __forceinline__ float mu_graph(const float* __restrict__ musX, const float* __restrict__ G, const KernelConsts& kc,
+                                          const float* rng, int k, int l) {
+    const float q = fqt(mu_off<D>(musX, G, kc, k, l), kc, rng, 2);
+    return (G != nullptr && kc.qmode >= 2) ? q + G[(size_t)k * D + l] : q;
+}
 // pis_l1 normaliser (smoe.py:1022-1027): start_pis, or the image-wide count of kernels with qpis > 0
 __device__ __forceinline__ float reg_pi_of(float reg_pi, const KernelConsts& kc, const float* rng) {
     return kc.kcount_norm ? kc.pis_l1_raw / fmaxf(rng[40], 1.0f) : reg_pi;
@@ -223,10 +236,10 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int m = 0; m < D; ++m) {
                 float cz = 0.0f;
                 if (ic) {
-                    cz = fqt(a.p.musX[(size_t)k * D + m], a.kc, a.qrng, 2);   // the centre itself: r = x - mu per pixel
+                    cz = mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, m);   // the centre itself: r = x - mu per pixel
                 } else {
 #pragma unroll
-                    for (int l = m; l < D; ++l) cz = fmaf(fqt(a.p.musX[(size_t)k * D + l], a.kc, a.qrng, 2), SQ * A[l][m], cz);
+                    for (int l = m; l < D; ++l) cz = fmaf(mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l), SQ * A[l][m], cz);
                 }
                 r[L::O_CZ + m] = cz;
             }
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         float Aq[D][D], rr[D];
 #pragma unroll
         for (int l = 0; l < D; ++l) {
-            rr[l] = xh[l] - fqt(a.p.musX[(size_t)k * D + l], a.kc, a.qrng, 2);
+            rr[l] = xh[l] - mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
 #pragma unroll
             for (int m = 0; m <= l; ++m) {
                 Aq[l][m] = fqt((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, a.qrng, (l == m) ? 0 : 1);
@@ -599,8 +612,8 @@ __device__ __forceinline__ void kernel_step(const SharedAdamArgs& a, int k, bool
     S.pi = fqv(S.pi_raw, a.kc, 3);
 #pragma unroll
     for (int l = 0; l < D; ++l) {
-        S.mu_raw[l] = a.p.musX[(size_t)k * D + l];
-        S.mu[l] = fqt(S.mu_raw[l], a.kc, a.qrng, 2);
+        S.mu_raw[l] = mu_off<D>(a.p.musX, a.mus_grid, a.kc, k, l);        // the quantised variable (use_diff_center: the offset)
+        S.mu[l] = mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
 #pragma unroll
         for (int m = 0; m < D; ++m) {
             S.Araw[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
@@ -747,7 +760,7 @@ __device__ __forceinline__ void workgroup_reduce(float (&v)[NV], float* s_part /
 }
 
 template <int D, int C>
-__device__ __forceinline__ void ranges_of_image(const smoe_params& p, int K, const KernelConsts& kc, float* qrng, float* s_part, float* s_out) {
+__device__ __forceinline__ void ranges_of_image(const smoe_params& p, const float* __restrict__ G, int K, const KernelConsts& kc, float* qrng, float* s_part, float* s_out) {
     constexpr float INF = __builtin_huge_valf();
     float ex[11];                                   // lo[0..4], -hi[5..9] of this thread's kernels; [10]: -count
 #pragma unroll
@@ -759,7 +772,7 @@ __device__ __forceinline__ void ranges_of_image(const smoe_params& p, int K, con
         auto see = [&](int t, float x) { ex[t] = fminf(ex[t], x); ex[5 + t] = fminf(ex[5 + t], -x); };
 #pragma unroll
         for (int l = 0; l < D; ++l) {
-            see(2, p.musX[(size_t)k * D + l]);
+            see(2, mu_off<D>(p.musX, G, kc, k, l));
 #pragma unroll
             for (int m = 0; m <= l; ++m)
                 see((l == m) ? 0 : 1, (l == m) ? p.A_diagonal[((size_t)k * D + l) * D + m] : p.A_corr[((size_t)k * D + l) * D + m]);
@@ -797,7 +810,7 @@ template <int D, int C>
 __global__ void __launch_bounds__(RG_THREADS) shared_ranges_kernel(SharedRangesArgs a) {
     __shared__ float s_part[(RG_THREADS / 64) * 20];
     __shared__ float s_out[20];
-    ranges_of_image<D, C>(a.p, a.K, a.kc, a.qrng, s_part, s_out);
+    ranges_of_image<D, C>(a.p, a.mus_grid, a.K, a.kc, a.qrng, s_part, s_out);
 }
 
 // quantization_mode 3: fake_quant_with_min_max_vars sends the gradient of what falls outside the nudged range to its
@@ -887,7 +900,7 @@ __global__ void shared_readmit_kernel(SharedReadmitArgs a) {
         for (int l = D - 1; l >= 0; --l) {
             const int sel = rem % 3;
             rem /= 3;
-            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - fqt(a.p.musX[(size_t)k * D + l], a.kc, a.qrng, 2);
+            r[l] = a.probes[((size_t)b * D + l) * 3 + sel] - mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
         }
         float maha = 0.0f;
 #pragma unroll

@@ -181,6 +181,15 @@ class BlockEngine:
     def set_tiling(self, lanes_per_block: int):
         _lib.check(self.lib.smoe_set_tiling(self._h, lanes_per_block))
 
+    def set_center_grid(self, grid: Optional[torch.Tensor]):
+        """use_diff_center with quantization_mode 2 / 3: the kernel-grid centres [B, K, d] (float32, on the device, laid
+        out like musX) the trained offsets are relative to, or None to clear.  The engine keeps a reference."""
+        if grid is not None:
+            assert grid.dtype == torch.float32 and grid.is_contiguous() and grid.device == self.device
+            assert grid.ndim == 3 and tuple(grid.shape[1:]) == (self.cfg.kernels, len(self.cfg.block_shape))
+        self._center_grid = grid
+        _lib.check(self.lib.smoe_set_center_grid(self._h, _ptr(grid)))
+
     def fit_occupancy(self, B: int) -> int:
         return int(self.lib.smoe_fit_occupancy(self._h, B))
 
@@ -421,6 +430,15 @@ class SharedEngine:
             assert tuple(loss_w.shape) == (self.num_batches, self.batch_pixels)
         self._loss_w = loss_w
         _lib.check(self.lib.smoe_shared_set_loss_weights(self._h, _ptr(loss_w)))
+
+    def set_center_grid(self, grid: Optional[torch.Tensor]):
+        """use_diff_center with quantization_mode 2 / 3: the kernel-grid centres [K, d] (float32, on the device) the trained
+        offsets are relative to, or None to clear.  The engine keeps a reference."""
+        if grid is not None:
+            assert grid.dtype == torch.float32 and grid.is_contiguous() and grid.device == self.device
+            assert tuple(grid.shape) == (self.cfg.kernels, len(self.cfg.image_shape))
+        self._center_grid = grid
+        _lib.check(self.lib.smoe_shared_set_center_grid(self._h, _ptr(grid)))
 
     def grad_buffer(self) -> torch.Tensor:
         """The gradient accumulation buffer as a float64 device tensor view (for the all-reduce

@@ -108,9 +108,6 @@ class Smoe:
                 raise NotImplementedError(f"Smoe({name}=True) is outside the per-block hot path (SURVEY section 8)")
         if quantization_mode not in (0, 1, 2, 3):
             raise ValueError("quantization_mode must be 0, 1, 2 or 3")                # smoe_test.py:298-301
-        if quantization_mode >= 2 and use_diff_center:
-            raise NotImplementedError("fake-quantised centre OFFSETS (use_diff_center with quantization_mode 2/3) "
-                                      "are not built: the engine works on absolute centres")
         if add_kernel_slots:
             raise NotImplementedError("progressive kernel adding changes K over time; not part of the hot path")
         if overlap_of_batches:
@@ -291,6 +288,15 @@ class Smoe:
                 self._engine.close()
             self._engine = self._engine_factory(cfg, self._device)
             self._engine_key = key
+            self._hand_over_center_grid()
+
+    def _hand_over_center_grid(self):
+        """use_diff_center with quantization_mode 2 / 3: the graph quantises the OFFSETS (smoe.py:746-747), so the engine
+        needs the kernel grid its ``musX`` (= grid + offset) is relative to."""
+        if getattr(self, "_mus_grid", None) is None or int(self.quantization_mode) < 2:
+            return
+        self._mus_grid_dev = torch.from_numpy(np.ascontiguousarray(self._mus_grid, dtype=np.float32)).to(self._engine.device)
+        self._engine.set_center_grid(self._mus_grid_dev)
 
     @property
     def kernel_list_per_batch(self) -> List[np.ndarray]:
@@ -717,8 +723,6 @@ class SharedSmoe:
             raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images")
         self.only_y_gamma = bool(only_y_gamma) and self.use_yuv          # smoe_test.py:43-44, smoe.py:725-729
         self.use_diff_center = bool(use_diff_center)
-        if quantization_mode >= 2 and use_diff_center:
-            raise NotImplementedError("fake-quantised centre OFFSETS are not built: the engine works on absolute centres")
         self.overlap = int(overlap_of_batches)                            # smoe.py:244
         if batch_size is None or batch_size[0] is None:
             bs = blk.get_batch_shape(start_batches, tuple(image.shape[:d]) + (d + image.shape[-1],))[:-1]
@@ -809,6 +813,9 @@ class SharedSmoe:
                 self._engine.close()
             self._engine = self._factory(cfg, self._device)
             self._engine_key = key
+            if self._mus_grid is not None and self.quantization_mode >= 2:   # the graph quantises the OFFSETS (smoe.py:746-747)
+                self._mus_grid_dev = torch.from_numpy(np.ascontiguousarray(self._mus_grid, dtype=np.float32)).to(self._engine.device)
+                self._engine.set_center_grid(self._mus_grid_dev)
             if getattr(self, "_loss_w", None) is not None:                # a re-created engine needs the weights again
                 self._engine.set_loss_weights(self._loss_w)
 

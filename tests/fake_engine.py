@@ -53,6 +53,9 @@ class OracleEngine:
     def close(self):
         pass
 
+    def set_center_grid(self, grid):
+        self.ocfg.mus_grid = None if grid is None else grid.numpy()
+
     def new_adam_state(self, params):
         return _State(params, self.cfg.beta1, self.cfg.beta2)
 
@@ -221,6 +224,9 @@ class OracleSharedEngine:
 
     def set_loss_weights(self, loss_w):
         self._loss_w = None if loss_w is None else loss_w.numpy()
+
+    def set_center_grid(self, grid):
+        self.ocfg.mus_grid = None if grid is None else grid.numpy()[None]
 
     def _lw(self, first_batch, nb):
         lw = getattr(self, "_loss_w", None)

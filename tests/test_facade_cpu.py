@@ -108,8 +108,7 @@ def test_checkpoint_restore_and_model_pickle(tmp_path):
 
 def test_options_outside_the_hot_path_are_refused():
     img = _image(16, 16)
-    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True},
-               {"quantization_mode": 3, "use_diff_center": True}):
+    for kw in ({"overlap_of_batches": 2}, {"add_kernel_slots": 4}, {"train_svs": True}):
         with pytest.raises(NotImplementedError):
             Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], engine_factory=OracleEngine, **kw)
     with pytest.raises(AssertionError):
@@ -533,6 +532,36 @@ def test_radial_steering_with_a_quantisation_mode(mode):
     if mode == 1:
         assert [i for i, _ in s.get_qlosses()] == [0, 2, 4]
         assert s.rparams["A_diagonal"].shape == (4, 4, 2, 2) and not s.rparams["A_corr"].any()
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_fake_quantised_centre_offsets_through_the_facade(mode):
+    """use_diff_center with quantization_mode 2 / 3: the facade hands the kernel grid to the engine, the fit follows
+    oracle.fit with ``mus_grid``; get_params() reports the offsets."""
+    img = _image(32, 32, seed=15)
+    kw = dict(quantization_mode=mode, quantize_pis=True, bit_depths=[14, 10, 8, 10, 10], lower_bounds=[-60, -.06, -1, 0, -4],
+              upper_bounds=[60, .08, 2, 2, 4])
+    s = Smoe(img, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, use_diff_center=True, train_inverse_cov=False,
+             engine_factory=OracleEngine, **kw)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    s.train(4, val_iter=2)
+    tb, _ = blk.image_to_blocks(img, (16, 16))
+    p0 = o.init_params(tb, [2, 2])
+    cfg = o.OracleConfig(block_shape=(16, 16), channels=1, kernels=4, lr_steer=0.05, mus_grid=p0["musX"].copy(),
+                         quantization_mode=mode, quantize_pis=True, bit_depths=tuple(kw["bit_depths"]),
+                         lower_bounds=tuple(kw["lower_bounds"]), upper_bounds=tuple(kw["upper_bounds"]))
+    pn, _, _ = o.fit(p0, tb.reshape(4, -1, 1), o.block_coords((16, 16)), cfg, 4, val_iter=2, dtype=np.float32)
+    got = s.get_params()
+    assert np.allclose(got["musX"], pn["musX"] - cfg.mus_grid, atol=1e-6) and np.abs(got["musX"]).max() > 0
+    for k in ("pis", "nu_e", "A_diagonal"):
+        assert np.allclose(got[k], pn[k], rtol=1e-5, atol=1e-6), k
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    g = SharedSmoe(img, kernels_per_dim=[3, 3], batch_size=[16, 16], use_diff_center=True, train_inverse_cov=False,
+                   engine_factory=OracleSharedEngine, **kw)
+    g.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.05))
+    g.train(3, val_iter=3)
+    assert np.abs(g.get_params()["musX"]).max() > 0 and g.get_losses()[-1][1] < g.get_losses()[0][1] * 1.5
 
 
 def test_shared_facade_with_the_ssim_loss():

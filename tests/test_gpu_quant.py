@@ -179,3 +179,66 @@ def test_quant_configuration_errors():
     assert e.value.code == _lib.SMOE_ERR_INVALID
     with pytest.raises(_lib.SmoeError):
         BlockEngine(EngineConfig(block_shape=(16, 16), channels=1, kernels=4, quantize_pis=True, bit_depths=(20, 18, 6, 30, 10)))
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("shape,C,kpd,yuv,tiling", [((16, 16), 1, [2, 2], False, 16), ((16, 16), 1, [2, 2], False, 64),
+                                                     ((16, 16), 3, [2, 2], True, 16), ((16, 16, 4), 3, [2, 2, 1], True, 64)])
+def test_fake_quantised_centre_offsets(shape, C, kpd, yuv, tiling, mode):
+    """use_diff_center with quantization_mode 2 / 3 (smoe.py:390-394,746-747): the quantised variable is the OFFSET of a
+    centre from the kernel grid, the graph reads fake_quant(offset) + grid.  The engine keeps grid + offset in musX and is
+    handed the grid (smoe_set_center_grid): forward, gradients through the offsets' masks / routing, readmission."""
+    B = 23
+    kw = dict(quantization_mode=mode, quantize_pis=True, bit_depths=(14, 10, 8, 10, 10),
+              lower_bounds=(-60, -.06, -1, 0, -4), upper_bounds=(60, .08, 2, 2, 4))
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 70 + C + mode, pis_l1=0.2, u_l1=0.003, **kw)
+    d = len(shape)
+    p["A_corr"] = p["A_corr"] * np.tril(np.ones((d, d), np.float32), -1)
+    rng = np.random.default_rng(4)
+    grid = o.init_params(tgt.reshape((B,) + tuple(shape) + (C,)), kpd)["musX"].astype(np.float32)
+    off = rng.uniform(-0.05, 0.05, size=grid.shape).astype(np.float32)
+    off[3, 1, 0] = 0.09                                # outside the fixed offset range of mode 2: clamped, no gradient
+    p["musX"] = (grid + off).astype(np.float32)
+    cfg = o.OracleConfig(**{**cfg.__dict__, "mus_grid": grid})
+    active = np.ones((B, K), bool)
+    eng = _engine(shape, C, K, use_yuv=yuv, pis_l1=0.2, u_l1=0.003, **kw)
+    eng.set_tiling(tiling)
+    gdev = torch.from_numpy(grid).cuda()
+    eng.set_center_grid(gdev)
+    dp = _to_dev(p)
+    act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+    T = _planar(tgt)
+    fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
+    recon = np.transpose(fw["recon"].cpu().numpy(), (0, 2, 1))
+    ref = o.forward(p, tgt, coords, active, cfg, None, np.float32, want_grads=True, q_override=recon)
+    frac = (np.clip(ref["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie_q = (frac < 3e-4) | (frac > 1 - 3e-4)
+    plain = o.forward(p, tgt, coords, active, cfg, None, np.float32)
+    assert (np.abs(recon - plain["recon"])[~tie_q] < 1e-7).all()
+    # without the grid the engine would quantise the centres themselves: a different image
+    eng.set_center_grid(None)
+    other = np.transpose(eng.forward(T, dp, act, want_recon=True, update_active=False)["recon"].cpu().numpy(), (0, 2, 1))
+    assert np.abs(other - recon).max() > 1e-3
+    eng.set_center_grid(gdev)
+    assert np.abs(fw["loss"].cpu().numpy() - ref["loss"]).max() < 2e-5 * max(1.0, np.abs(ref["loss"]).max())
+    st = eng.new_adam_state(dp)
+    eng.fit(T, dp, st, act, 1)
+    torch.cuda.synchronize()
+    tie = (np.abs(ref["w"] - 0.5 / 256) < 1e-6).any(axis=(1, 2))
+    edge = ((np.abs(ref["y"]) < 1e-6) | (np.abs(ref["y"] - 1) < 1e-6)).any(axis=(1, 2))
+    clean = ~(tie | edge)
+    assert clean.sum() >= B // 2
+    m = _to_host(st.m)
+    for name in o.PARAM_NAMES:
+        g_ref = ref["grads"][name][clean]
+        err = np.abs(m[name][clean] / 0.1 - g_ref).max() / (np.abs(g_ref).max() + 1e-30)
+        assert err < 1e-4, (name, err)
+    if mode == 2:
+        assert m["musX"][3, 1, 0] == 0.0
+    # readmission runs on the same quantised centres
+    got = _to_host(dp)
+    empty = torch.zeros_like(act)
+    eng.update_kernel_list(dp, empty)
+    want = o.readmit(got, np.zeros((B, K), bool), cfg, np.float32)
+    assert np.array_equal(_bits_to_mask(empty.cpu().numpy().view(np.uint32), K), want)
+    eng.close()

@@ -572,6 +572,55 @@ def test_shared_radial_steering_with_ranges_from_the_data():
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_shared_fake_quantised_centre_offsets(mode):
+    """use_diff_center with quantization_mode 2 / 3 in the shared-kernel mode (smoe_shared_set_center_grid)."""
+    shape, bshape, C, kpd = (64, 64), (16, 16), 1, [4, 4]
+    kw = dict(pis_l1=0.05, u_l1=0.002, quantization_mode=mode, quantize_pis=True, bit_depths=(14, 10, 8, 10, 10),
+              lower_bounds=(-60, -.03, -1, 0, -4), upper_bounds=(60, .04, 2, 2, 4))
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, False, perturb=True, **kw)
+    d = len(shape)
+    p["A_corr"] = p["A_corr"] * np.tril(np.ones((d, d), np.float32), -1)
+    from steered_mixture_of_experts_amd import blocks as sblk
+    grid = sblk.init_block_params(img[None], kpd, True, False)["musX"][0].astype(np.float32)
+    rng = np.random.default_rng(9)
+    off = rng.uniform(-0.025, 0.025, size=grid.shape).astype(np.float32)
+    off[5, 0] = 0.05                                    # outside the fixed offset range of mode 2
+    p["musX"] = (grid + off)[None].astype(np.float32)
+    cfg = o.OracleConfig(**{**cfg.__dict__, "mus_grid": grid[None]})
+    lists = np.ones((NB, K), bool)
+    eng = _engine(shape, bshape, C, K, False, **kw)
+    gdev = torch.from_numpy(grid).cuda()
+    eng.set_center_grid(gdev)
+    dp = _dev(p)
+    dl = eng.new_lists()
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    fw = eng.forward(T, dp, dl, want_recon=True, update_lists=False)
+    recon = fw["recon"].cpu().numpy().transpose(0, 2, 1)
+    ref = o.shared_pass(p, tgt, coords, lists, cfg, np.float32)
+    frac = (np.clip(ref["y"], 0, 1) * 255 + 0.5) % 1.0
+    tie = (frac < 3e-4) | (frac > 1 - 3e-4)
+    assert (np.abs(recon - ref["recon"])[~tie] < 1e-7).all()
+    f32 = o.forward(o._bcast(p, NB), tgt, coords, lists, cfg, None, np.float32, want_grads=True, q_override=recon)
+    g32 = {k: v.sum(axis=0) for k, v in f32["grads"].items()}
+    st = eng.new_adam_state(dp)
+    eng.accumulate(T, dp, dl)
+    eng.apply(dp, st)
+    torch.cuda.synchronize()
+    m = {k: v.cpu().numpy() for k, v in st.m.items()}
+    for name in o.PARAM_NAMES:
+        scale = np.abs(g32[name]).max() + 1e-30
+        assert np.abs(m[name] / 0.1 - g32[name]).max() / scale < 1e-4, name
+    if mode == 2:
+        assert not m["musX"][5, 0]
+    empty = torch.zeros_like(dl)
+    got = {k: v.cpu().numpy()[None] for k, v in dp.items()}
+    eng.update_kernel_list(dp, empty)
+    want = o.shared_readmit(got, np.zeros((NB, K), bool), coords, cfg, np.float32)
+    assert np.array_equal(_mask(empty.cpu().numpy().view(np.uint32), K), want)
+    eng.close()
+
+
 def test_gradient_buffer_goes_through_an_rccl_all_reduce():
     """Multi-GPU shared mode: the accumulated fp64 gradient buffer (library memory wrapped as a torch tensor) is what
     torch.distributed all-reduces between smoe_shared_accumulate and smoe_shared_apply.  One rank is all this box has:
