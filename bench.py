@@ -49,7 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--image", type=int, nargs="+", default=None,
                     help="strong scaling: image shape (H W [T]); its blocks are split over the ranks")
     ap.add_argument("--iters-per-launch", type=int, default=100)
-    ap.add_argument("--tiling", type=int, default=0, help="lanes per block: 0 auto, 16, 64")
+    ap.add_argument("--tiling", type=int, default=0, help="lanes per block: 0 auto, 16, 32, 64; 128 = 64 lanes with one block on both wavefronts of a workgroup")
     ap.add_argument("--block-shape", type=int, nargs="+", default=[16, 16])
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--kernels-per-dim", type=int, nargs="+", default=[2, 2])
@@ -440,7 +440,10 @@ def worker(args):
                   "value": round(v1, 1), "unit": "Mpixel-iters/s", "ms_total": round(ms1, 4), "reps": len(ms_list),
                   "contract_frac": round(v1 * 1e6 * bpi1 / 1e9 / HBM_PEAK_GBS, 4),
                   "kernel_variant": eng1.fit_variant(Bs),
-                  "note": "1024 blocks = one wavefront per SIMD at most; latency bound (DESIGN.md section 4)"}
+                  "note": "1024 blocks = one wavefront per SIMD: each block runs on BOTH wavefronts of a workgroup "
+                          "(fit_kernel PAIR, the library's choice up to 1024 blocks); a lone wavefront issues one VALU "
+                          "instruction per ~5.6 cycles, so the ~770 instructions per iteration outside the pixel loop bound "
+                          "it (DESIGN.md section 4)"}
         eng1.close()
 
     if rank == 0:

@@ -2284,11 +2284,22 @@ size_t lds_bytes_ssim(int N, bool has_lw, int bh, int bw, int bt, bool hq) {
 }
 
 template <int D, int C, int K, int G, int WAVES>
-int fit_occupancy(int N, bool has_lw) {
+int fit_occupancy(int N, bool has_lw, int hoist, bool pair) {
     using T = Tile<D, C, K, G, WAVES>;
     int nb = 0;
-    auto kern = fit_kernel<D, C, K, G, WAVES, 1>;
-    const size_t shm = T::bytes(N, has_lw, D - 1);
+    auto kern = fit_kernel<D, C, K, G, WAVES, 0>;
+    int hl = 0;
+    if (hoist >= 1) { kern = fit_kernel<D, C, K, G, WAVES, 1>; hl = 1; }
+    if (D == 3 && hoist >= 2) { kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1)>; hl = 2; }
+    if constexpr (G == 64 && WAVES == 2) {
+        if (pair) {
+            kern = fit_kernel<D, C, K, G, WAVES, 0, false, false, false, true>;
+            if (hl == 1) kern = fit_kernel<D, C, K, G, WAVES, 1, false, false, false, true>;
+            if (hl == 2) kern = fit_kernel<D, C, K, G, WAVES, (D == 3 ? 2 : 1), false, false, false, true>;
+        }
+    }
+    size_t shm = T::bytes(N, has_lw, D - hl);
+    if (T::wants_owner_post(N)) shm += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, shm) != hipSuccess) return -1;
     return nb * WAVES;       // resident wavefronts per CU

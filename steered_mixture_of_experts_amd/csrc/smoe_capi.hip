@@ -157,8 +157,8 @@ bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
     if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov) return false;
     if (h->force_pair) return h->force_pair > 0;
     if (num_blocks > PAIR_MAX_BLOCKS) return false;
-    if (h->pair_occ < 0) h->pair_occ = v->fit_waves_per_cu(h->N, false);     // wavefronts per CU of the 64-lane kernel
-    return h->pair_occ >= 8;
+    if (h->pair_occ < 0) h->pair_occ = v->fit_waves_per_cu(h->N, false, hoist_level(h, v), true);   // of the PAIR kernel itself
+    return h->pair_occ >= 8;                                   // two wavefronts per SIMD can be resident together
 }
 
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
@@ -404,7 +404,7 @@ int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks) {
     const smoe::Variant* v = find_variant(h, num_blocks, false);
     if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_fit_occupancy: no variant");
     if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SMOE_ERR_HIP, "hipSetDevice");
-    return v->fit_waves_per_cu(h->N, false);
+    return v->fit_waves_per_cu(h->N, false, hoist_level(h, v), false);
 }
 
 int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const float* loss_w,

@@ -114,7 +114,7 @@ struct Variant {
     hipError_t (*fit)(const FitArgs&, int hoist_level, hipStream_t);
     hipError_t (*fwd)(const FwdArgs&, hipStream_t);
     size_t (*lds_bytes)(int N, bool has_lw, bool quant_image);
-    int (*fit_waves_per_cu)(int N, bool has_lw);
+    int (*fit_waves_per_cu)(int N, bool has_lw, int hoist_level, bool pair);   // of the kernel smoe_fit would launch
     hipError_t (*fit_ssim)(const FitArgs&, int hoist_level, hipStream_t);   // ssim_opt (D == 2, G == 64)
     hipError_t (*fwd_ssim)(const FwdArgs&, hipStream_t);
     size_t (*lds_bytes_ssim)(int N, bool has_lw, int bh, int bw, int bt, bool quant_image);
