@@ -105,6 +105,14 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 // ---------------------------------------------------------------------------
 // sqrt(0.5 * log2(e)): with A' = SQ * A, |A'^T r|^2 = maha * 0.5*log2(e), so
 // exp(-maha/2) = exp2(-|z'|^2) and the per-kernel scale multiply disappears.
+// 64-lane tiling: cross-lane reduction in registers (reduce_slots_regs) instead of the LDS transpose.  Built, parity-green
+// (224 GPU tests) and measured SLOWER (scripts/pair_check.py, one session): ONE image 0.303 -> 0.328 ms per 100 iterations,
+// its two-wavefront form 0.282 -> 0.294, 1 020 blocks of 16x16x4 RGB 1.13 -> 1.27 ms; only 32x32 / K = 8 gained (1.39 ->
+// 1.34 ms).  The swaps and the four dependent DPP rotations per slot cost more than the 17 LDS waits they remove.  Off;
+// make EXTRA=-DSMOE_REGRED=1 builds it.
+#ifndef SMOE_REGRED
+#define SMOE_REGRED 0
+#endif
 #define SMOE_SQ 0.84932180028801904272f
 #define SMOE_INV_SQ 1.17740022503374817543f
 
@@ -727,8 +735,17 @@ struct Tile {
     static constexpr int NCHUNK = (Lt::NSLOT + CH - 1) / CH;
     // slots owned per lane: all UL lanes of a row hold its total after the exchange; lane u of them owns the slot of the
     // rounds q with q % UL == u
-    static constexpr int SPL = (NROUND + UL - 1) / UL;
+    // G = 64: the reduction runs in registers instead (reduce_slots_regs: v_permlane32_swap / v_permlane16_swap halve the
+    // slot set twice, DPP rotations finish inside the rows of 16 lanes): row r = lane / 16 ends up with the totals of the
+    // RM slots [r RM, (r + 1) RM), lane c of the row owns slots r RM + c, r RM + c + 16, ...
+    static constexpr bool REGRED = (G == 64) && (SMOE_REGRED != 0);
+    static constexpr int RM = (Lt::NSLOT + 3) / 4;
+    static constexpr int SPL = REGRED ? (RM + 15) / 16 : (NROUND + UL - 1) / UL;
     __host__ __device__ static constexpr int slot_of(int sub, int s) {
+        if (REGRED) {
+            const int i = (sub % 16) + 16 * s;
+            return (i < RM) ? (sub / 16) * RM + i : Lt::NSLOT;          // NSLOT = no slot
+        }
         return (UL * s + (sub % UL)) * RPR + sub / UL;
     }
     static constexpr int THREADS = WAVES * 64;
@@ -873,9 +890,55 @@ __device__ __forceinline__ int tile_index(int j, int lb) {
 // partials of these slots as rows (conflict-free 4-byte stores); in each round every lane then sums one unit of one
 // row with 16-byte reads (rows are padded by 4 floats so the b128 reads do not conflict).  All reads of a pass are
 // issued from clamped addresses without branches, so they go out back to back behind ONE wait.
+// G = 64, in registers.  A swap exchanges the upper half of its first operand with the lower half of its second
+// (v_permlane32_swap: halves of the wavefront; v_permlane16_swap: odd / even rows of 16 lanes), so ONE swap + ONE add
+// reduce TWO slots over the pair of lanes: the first slot's sum stays in the lower half, the second's in the upper.  Two
+// such levels leave row r of the wavefront with the partial sums of slots [r RM, (r + 1) RM) over lanes {c, c+16, c+32,
+// c+48}; four DPP row rotations (8, 4, 2, 1) finish them inside the row.  No LDS traffic and no waits (the transpose costs
+// 223 instructions + 17 waits for 42 slots against ~130 here) -- and slower all the same: see SMOE_REGRED.
 template <int D, int C, int K, int G, int WAVES, int FIRST>
-__device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, float* __restrict__ scratch_wave,
-                                             int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
+__device__ __forceinline__ void reduce_slots_regs(const float* __restrict__ acc, int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
+    using T = Tile<D, C, K, G, WAVES>;
+    using Lt = Layout<D, C, K>;
+    constexpr int NS = Lt::NSLOT, M = T::RM;
+    auto wanted = [](int j) constexpr { return j >= FIRST && j < NS; };
+    float v1[2 * M];
+#pragma unroll
+    for (int j = 0; j < 2 * M; ++j) {
+        v1[j] = 0.0f;
+        if (!wanted(j) && !wanted(j + 2 * M)) continue;                    // compile-time
+        const float x = (j < NS) ? acc[j] : 0.0f;
+        const float y = (j + 2 * M < NS) ? acc[j + 2 * M] : 0.0f;
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        v1[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    float v2[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        v2[i] = 0.0f;
+        if (!wanted(i) && !wanted(i + M) && !wanted(i + 2 * M) && !wanted(i + 3 * M)) continue;
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v1[i]), __float_as_uint(v1[i + M]), false, false);
+        float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xf, 0xf, true));    // row_ror:8
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xf, 0xf, true));    // row_ror:4
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xf, 0xf, true));    // row_ror:2
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xf, 0xf, true));    // row_ror:1
+        v2[i] = t;
+    }
+    const int c = lane & 15;
+#pragma unroll
+    for (int s = 0; s < T::SPL; ++s) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (16 * s + i < M) t = (c == i) ? v2[16 * s + i] : t;
+        total[s] = t;
+    }
+}
+
+template <int D, int C, int K, int G, int WAVES, int FIRST>
+__device__ __forceinline__ void reduce_slots_lds(const float* __restrict__ acc, float* __restrict__ scratch_wave,
+                                                 int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
     using T = Tile<D, C, K, G, WAVES>;
     using Lt = Layout<D, C, K>;
     // (opaque lane index: the row / unit / scratch addresses derived from it are loop invariant, and hoisted out of the
@@ -930,6 +993,13 @@ __device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, floa
         }
         wave_lds_sync();
     }
+}
+
+template <int D, int C, int K, int G, int WAVES, int FIRST>
+__device__ __forceinline__ void reduce_slots(const float* __restrict__ acc, float* __restrict__ scratch_wave,
+                                             int lane, float (&total)[Tile<D, C, K, G, WAVES>::SPL]) {
+    if constexpr (Tile<D, C, K, G, WAVES>::REGRED) reduce_slots_regs<D, C, K, G, WAVES, FIRST>(acc, lane, total);
+    else reduce_slots_lds<D, C, K, G, WAVES, FIRST>(acc, scratch_wave, lane, total);
 }
 
 // ---------------------------------------------------------------------------
