@@ -44,7 +44,7 @@ def one_case(rng, idx):
         kw.update(quantization_mode=mode, quantize_pis=True, **QKW)
     elif rng.random() < 0.5:
         kw["quantize_pis"] = True
-    ssim = d == 2 and not generic and rng.random() < 0.3
+    ssim = not generic and rng.random() < 0.3 and (d == 2 or (C == 3 and min(shape) >= 5))     # 3-d: the FULL triple (3, 3, 4)
     if ssim:
         kw["ssim_opt"] = True
     if C == 3 and yuv and rng.random() < 0.3:
@@ -54,10 +54,11 @@ def one_case(rng, idx):
     if rng.random() < 0.2 and not mode:
         kw["kernel_count_as_norm_l1"] = True
         kw.setdefault("pis_l1", 0.05)
-    if rng.random() < 0.15 and mode != 3:
+    if rng.random() < 0.15:
         kw["radial_as"] = True
+    centred = mode >= 2 and rng.random() < 0.3              # use_diff_center: the quantised variable is musX - grid
     B = int(rng.integers(3, 40))
-    tiling = int(rng.choice([0, 16, 32, 64]))
+    tiling = int(rng.choice([0, 16, 32, 64, 128]))
     desc = dict(idx=idx, shape=shape, C=C, kpd=kpd, yuv=yuv, B=B, tiling=tiling, **kw)
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, yuv, B, 1000 + idx, **kw)
     dd = len(shape)
@@ -70,6 +71,12 @@ def one_case(rng, idx):
     if kw.get("train_inverse_cov"):
         p["A_diagonal"] = (p["A_diagonal"] ** 2).astype(np.float32)
         p["A_corr"] = (p["A_corr"] * 0.3).astype(np.float32)
+    grid = None
+    if centred:
+        grid = o.init_params(tgt.reshape((B,) + tuple(shape) + (C,)), kpd)["musX"].astype(np.float32)
+        p["musX"] = (grid + rng.uniform(-0.05, 0.05, size=grid.shape)).astype(np.float32)
+        cfg = o.OracleConfig(**{**cfg.__dict__, "mus_grid": grid})
+        desc["centred"] = True
     active = np.ones((B, K), bool)
     try:
         eng = _engine(shape, C, K, use_yuv=yuv, **kw)
@@ -84,6 +91,10 @@ def one_case(rng, idx):
             except Exception:
                 eng.set_tiling(0)
         dp = _to_dev(p)
+        gdev = None
+        if grid is not None:
+            gdev = torch.from_numpy(grid).cuda()
+            eng.set_center_grid(gdev)
         act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
         T = _planar(tgt)
         fw = eng.forward(T, dp, act, want_recon=True, update_active=False)
