@@ -113,6 +113,9 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #ifndef SMOE_REGRED
 #define SMOE_REGRED 0
 #endif
+#ifndef SMOE_NT_STORES
+#define SMOE_NT_STORES 1
+#endif
 #define SMOE_SQ 0.84932180028801904272f
 #define SMOE_INV_SQ 1.17740022503374817543f
 
@@ -1795,11 +1798,28 @@ __global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
     }
 }
 
+// Output planes are written once and not read again by the kernel: 16-byte non-temporal stores (no L2 write-allocate
+// for lines nobody will hit): all outputs of the grayscale headline batch 99 -> 71 us (4.4 -> 6.1 TB/s).  Measured and NOT
+// kept: non-temporal DWORD stores on the three-channel path (170 -> 201 us) and non-temporal loads of the targets
+// (three-channel loss-only pass 66 -> 76 us).
+typedef float smoe_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float* __restrict__ p, const float4& v) {
+#if SMOE_NT_STORES
+    smoe_f4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<smoe_f4*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // forward (evaluation) kernel
 // ---------------------------------------------------------------------------
 // HL: hoisting level as in fit_kernel (the launcher passes the same rule); the SSIM kernels run with HL = 0.
-template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false, bool IC = false, int HL = 0>
+// OM: 0 = one kernel for both kinds of launch; 1 = loss-only launches, 2 = launches with per-pixel outputs (the plain
+// margin-loss kernels: each kind gets its own register allocation, so the four kept steps of the grouped 16-byte stores
+// no longer cost the loss-only pass a wavefront per SIMD and the three-channel kernels can group their stores too).
+template <int D, int C, int K, int G, int WAVES, bool SSIM = false, bool QUANT = false, bool IC = false, int HL = 0, int OM = 0>
 __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
@@ -1903,7 +1923,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
     for (int k = 0; k < K; ++k) flags[k] = 0ull;
     // OUT: the launch wants per-pixel outputs (reconstruction / gate planes / argmax); the loss-only pass of a validation
     // takes the store-free instance of the loop, two pixels per trip
-    const bool any_out = (a.recon != nullptr) || (a.gate_w != nullptr) || (a.argmax != nullptr) || SSIM;
+    const bool any_out = (OM == 0) ? ((a.recon != nullptr) || (a.gate_w != nullptr) || (a.argmax != nullptr) || SSIM) : (OM == 2);
     // `keep`: non-null = hand the pixel's outputs (q[C], wt[K], argmax as float) back to the caller instead of storing
     // them (the grouped 16-byte stores of the register path below)
     auto step_t = [&](int n, auto voted, auto want_out, const float (&t)[C], float lw, float* keep = nullptr) {
@@ -1969,7 +1989,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             // instead of four G-float segments (all outputs at 65 536 blocks: 125 -> see DESIGN 3.2).
             // (only while the four kept steps are <= 24 registers: with three channels they cost the loss-only instance of
             // this kernel a wavefront per SIMD -- 66 -> 84 us -- for 3.9 -> 4.0 TB/s on the output path)
-            constexpr bool GROUP_OK = (C + K + 1) * 4 <= 24;
+            constexpr bool GROUP_OK = (OM == 2) || (C + K + 1) * 4 <= 24;
             const bool grouped = GROUP_OK && OUT && ((N & 3) == 0) && ((G & 3) == 0);
             float* xs = s_scratch + grp * (4 * G);
 #pragma unroll
@@ -1991,14 +2011,14 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
                             const float4 v = turn(c);
-                            if (valid_b) *reinterpret_cast<float4*>(a.recon + ((size_t)b * C + c) * N + nb) = v;
+                            if (valid_b) store_stream(a.recon + ((size_t)b * C + c) * N + nb, v);
                         }
                     }
                     if (a.gate_w != nullptr) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             const float4 v = turn(C + k);
-                            if (valid_b) *reinterpret_cast<float4*>(a.gate_w + ((size_t)b * K + k) * N + nb) = v;
+                            if (valid_b) store_stream(a.gate_w + ((size_t)b * K + k) * N + nb, v);
                         }
                     }
                     if (a.argmax != nullptr) {
@@ -2080,7 +2100,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
         if (a.argmax != nullptr) {
             // every lane patches the bytes it wrote itself: four consecutive pixels per lane where the stores were grouped
             const uint32_t first = (newmask != 0u) ? (uint32_t)(__ffs(newmask) - 1) : 0u;
-            const bool grouped = ((C + K + 1) * 4 <= 24) && regt && ((N & 3) == 0) && ((G & 3) == 0);
+            const bool grouped = ((OM == 2) || (C + K + 1) * 4 <= 24) && regt && ((N & 3) == 0) && ((G & 3) == 0);
             for (int i = 0; i < pxl; ++i) {
                 if (grouped && (i | 3) < full) {
                     if ((i & 3) == 0) {
@@ -2198,10 +2218,18 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
-    auto kern = forward_kernel<D, C, K, G, WAVES>;
+    const bool outs = (a.recon != nullptr) || (a.gate_w != nullptr) || (a.argmax != nullptr);
+    auto kern = outs ? forward_kernel<D, C, K, G, WAVES, false, false, false, 0, 2> : forward_kernel<D, C, K, G, WAVES, false, false, false, 0, 1>;
     int hl = 0;
-    if (a.hoist >= 1) { kern = forward_kernel<D, C, K, G, WAVES, false, false, false, 1>; hl = 1; }
-    if (D == 3 && a.hoist >= 2) { kern = forward_kernel<D, C, K, G, WAVES, false, false, false, (D == 3 ? 2 : 1)>; hl = 2; }
+    if (a.hoist >= 1) {
+        kern = outs ? forward_kernel<D, C, K, G, WAVES, false, false, false, 1, 2> : forward_kernel<D, C, K, G, WAVES, false, false, false, 1, 1>;
+        hl = 1;
+    }
+    if (D == 3 && a.hoist >= 2) {
+        kern = outs ? forward_kernel<D, C, K, G, WAVES, false, false, false, (D == 3 ? 2 : 1), 2>
+                    : forward_kernel<D, C, K, G, WAVES, false, false, false, (D == 3 ? 2 : 1), 1>;
+        hl = 2;
+    }
     FwdArgs aa = a;
     aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
     const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
