@@ -45,8 +45,9 @@ def one_case(rng, idx):
     if rng.random() < 0.2:
         kw["kernel_count_as_norm_l1"] = True
         kw.setdefault("pis_l1", 0.05)
-    if rng.random() < 0.15 and mode != 3:
+    if rng.random() < 0.15:
         kw["radial_as"] = True
+    centred = mode >= 2 and rng.random() < 0.3             # use_diff_center: the quantised variable is musX - grid
     if yuv and rng.random() < 0.3:
         kw["only_y_gamma"] = True
     ov = int(rng.choice([0, 0, 0, 2, 3])) if d == 2 else 0
@@ -62,11 +63,21 @@ def one_case(rng, idx):
         p["A_diagonal"] = (p["A_diagonal"] ** 2).astype(np.float32)
         p["A_corr"] = (p["A_corr"] * 0.3).astype(np.float32)
     lists = np.ones((NB, K), bool)
+    grid = None
+    if centred:
+        grid = o.shared_init_params(img, kpd)["musX"][0].astype(np.float32)
+        p["musX"] = (grid + rng.uniform(-0.02, 0.02, size=grid.shape))[None].astype(np.float32)
+        cfg = o.OracleConfig(**{**cfg.__dict__, "mus_grid": grid[None]})
+        desc["centred"] = True
     try:
         eng = _engine(shape, bshape, C, K, yuv, overlap=ov, **kw)
     except Exception as e:
         return desc, "refused: " + str(e)[:90]
     try:
+        gdev = None
+        if grid is not None:
+            gdev = torch.from_numpy(grid).cuda()
+            eng.set_center_grid(gdev)
         dp = _dev(p)
         dl = eng.new_lists()
         T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
