@@ -609,9 +609,9 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         if (qrc != SMOE_OK) return fail(qrc, std::string("smoe_shared_create: ") + qmsg);
     }
     if (cfg->ssim_opt) {
-        if (cfg->dim != 2) return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt is built for 2-d batches only");
-        if (cfg->batch_shape[0] < 5 || cfg->batch_shape[1] < 5)
-            return fail(SMOE_ERR_INVALID, "smoe_shared_create: ssim_opt needs at least 5 pixels per batch axis (SYMMETRIC padding by 5)");
+        for (int ax = 0; ax < cfg->dim; ++ax)
+            if (cfg->batch_shape[ax] < 5)
+                return fail(SMOE_ERR_INVALID, "smoe_shared_create: ssim_opt needs at least 5 pixels per batch axis (SYMMETRIC padding by 5)");
     }
     if (!smoe::shared_supported(cfg->dim, cfg->channels, (int)Nb))
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: batch too large (<= 2048 pixels for 1 channel, <= 1024 for 3)");
@@ -670,7 +670,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     h->need_ranges = cfg->quantization_mode == 3 || cfg->kernel_count_as_norm_l1 != 0;
     if (cfg->ssim_opt) {
         const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
-                            smoe::shared_ssim_lds_bytes(cfg->channels, (int)Nb, cfg->batch_shape[0], cfg->batch_shape[1]);
+                            smoe::shared_ssim_lds_bytes(cfg->channels, (int)Nb, cfg->batch_shape[0], cfg->batch_shape[1], (cfg->dim == 3) ? cfg->batch_shape[2] : 0);
         if (need > 160u * 1024u) {
             delete h;
             return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt planes of this batch size do not fit in LDS");
@@ -685,10 +685,11 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     if (e == hipSuccess) e = hipMalloc(&h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess) e = hipMemset(h->d_qrng, 0, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess && cfg->ssim_opt) {
-        const int bh = cfg->batch_shape[0], bw = cfg->batch_shape[1];
-        std::vector<float> tabs((size_t)11 * (bh + bw));
+        const int bh = cfg->batch_shape[0], bw = cfg->batch_shape[1], bt = (cfg->dim == 3) ? cfg->batch_shape[2] : 0;
+        std::vector<float> tabs((size_t)11 * (bh + bw + bt));
         ssim_axis_table(bh, tabs.data());
         ssim_axis_table(bw, tabs.data() + (size_t)11 * bh);
+        if (bt) ssim_axis_table(bt, tabs.data() + (size_t)11 * (bh + bw));
         e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
     }

@@ -192,7 +192,7 @@ struct SharedRangesArgs {
 };
 
 size_t shared_lds_bytes(int D, int C, int K, int KW);
-size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw);
+size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw, int bt);
 bool shared_supported(int D, int C, int Nb);
 hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st);
 hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st);

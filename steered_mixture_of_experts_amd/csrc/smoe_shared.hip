@@ -123,7 +123,7 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // ---------------------------------------------------------------------------------------------
 // one pass over all batches
 // ---------------------------------------------------------------------------------------------
-// SSIM (ssim_opt, 2-d batches): loss_pixel = 1 - SSIM of the batch (smoe.py:980-1011); the quantised reconstruction and
+// SSIM (ssim_opt; 2-d batches, 3-d batches with the 11x11x11 window): loss_pixel = 1 - SSIM of the batch (smoe.py:980-1011); the quantised reconstruction and
 // the target of the batch go to LDS planes, the whole workgroup runs the SSIM stage of smoe_ssim.hip.h and reads dL/dq
 // back for the reverse sweep.
 // IC: train_inverse_cov (compile-time, it sits in the per-pixel gate).
@@ -411,14 +411,15 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     float loss_part = 0.0f, sse_part = 0.0f;
     if constexpr (SSIM) {
         float* s_ss = lds + a.ssim_off;
-        const int bh = a.batch_shape[0], bw = a.batch_shape[1];
+        const int bh = a.batch_shape[0], bw = a.batch_shape[1], bt = (D == 3) ? a.batch_shape[2] : 0;
         const float* s_Tr = s_ss;
         const float* s_Tc = s_ss + 11 * bh;
-        float* s_X = s_ss + ((11 * (bh + bw) + 3) & ~3);
+        const float* s_Tt = s_Tc + 11 * bw;               // 3-d batches: the taps of the third axis
+        float* s_X = s_ss + ((11 * (bh + bw + bt) + 3) & ~3);
         float* s_Y = s_X + C * Nb;
         float* s_Wa = s_Y + C * Nb;
-        float* s_Wb = s_Wa + 5 * Nb;
-        for (int i = tid; i < 11 * (bh + bw); i += SH_THREADS) s_ss[i] = a.ssim_T[i];
+        float* s_Wb = s_Wa + 5 * Nb;                      // 2-d: three planes, 3-d: five
+        for (int i = tid; i < 11 * (bh + bw + bt); i += SH_THREADS) s_ss[i] = a.ssim_T[i];
         bool ste[PXL][C];
 #pragma unroll
         for (int p = 0; p < PXL; ++p) {
@@ -437,7 +438,8 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             }
         }
         __syncthreads();
-        loss_part = ssim_block<C, TRAIN, SH_THREADS>(s_X, s_Y, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, Nb, tid);
+        if constexpr (D == 3) loss_part = ssim_block3<C, TRAIN, SH_THREADS>(s_X, s_Y, s_Wa, s_Wb, s_Tr, s_Tc, s_Tt, a.kc.sw, bh, bw, bt, Nb, tid);
+        else loss_part = ssim_block<C, TRAIN, SH_THREADS>(s_X, s_Y, s_Wa, s_Wb, s_Tr, s_Tc, a.kc.sw, bh, bw, Nb, tid);
 #pragma unroll
         for (int p = 0; p < PXL; ++p) {
             dot[p] = 0.0f;
@@ -931,9 +933,9 @@ size_t shared_lds_bytes(int D, int C, int K, int KW) {
     return sizeof(float) * (((size_t)K + SH_KC * SP + 4 * SH_KC * PK + K + 8 + 8 + KW + 3) & ~(size_t)3);
 }
 
-// ssim_opt: tap tables + X, Y [C][Nb] + Wa [5][Nb] + Wb [3][Nb] behind the regular carve-up
-size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw) {
-    return sizeof(float) * ((size_t)((11 * (bh + bw) + 3) & ~3) + (size_t)(2 * C + 8) * Nb);
+// ssim_opt: tap tables + X, Y [C][Nb] + Wa [5][Nb] + Wb [3][Nb] (3-d batches: a third table, Wb [5][Nb]) behind the regular carve-up
+size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw, int bt) {
+    return sizeof(float) * ((size_t)((11 * (bh + bw + bt) + 3) & ~3) + (size_t)(2 * C + (bt ? 10 : 8)) * Nb);
 }
 
 template <int D, int C, int PXL>
@@ -942,14 +944,10 @@ static hipError_t launch_pass_t(const SharedArgs& a, bool train, hipStream_t st)
     const bool ic = a.kc.inverse_cov != 0;
     auto kern = ic ? (train ? shared_pass_kernel<D, C, PXL, true, false, true> : shared_pass_kernel<D, C, PXL, false, false, true>)
                    : (train ? shared_pass_kernel<D, C, PXL, true> : shared_pass_kernel<D, C, PXL, false>);
-    if constexpr (D == 2) {
-        if (a.ssim) {
-            kern = ic ? (train ? shared_pass_kernel<D, C, PXL, true, true, true> : shared_pass_kernel<D, C, PXL, false, true, true>)
-                      : (train ? shared_pass_kernel<D, C, PXL, true, true> : shared_pass_kernel<D, C, PXL, false, true>);
-            shm += shared_ssim_lds_bytes(C, a.Nb, a.batch_shape[0], a.batch_shape[1]);
-        }
-    } else {
-        if (a.ssim) return hipErrorNotSupported;
+    if (a.ssim) {
+        kern = ic ? (train ? shared_pass_kernel<D, C, PXL, true, true, true> : shared_pass_kernel<D, C, PXL, false, true, true>)
+                  : (train ? shared_pass_kernel<D, C, PXL, true, true> : shared_pass_kernel<D, C, PXL, false, true>);
+        shm += shared_ssim_lds_bytes(C, a.Nb, a.batch_shape[0], a.batch_shape[1], (D == 3) ? a.batch_shape[2] : 0);
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;

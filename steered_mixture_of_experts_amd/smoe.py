@@ -719,8 +719,6 @@ class SharedSmoe:
         self.radial_as = bool(radial_as)                                   # smoe.py:429-434,714-719
         self.train_inverse_cov = bool(train_inverse_cov)                  # smoe.py:41: the constructor default is True
         self.ssim_opt = bool(ssim_opt)                                    # smoe.py:929,980-1011: 1 - SSIM per batch
-        if self.ssim_opt and image.ndim - 1 != 2:
-            raise NotImplementedError("SharedSmoe(ssim_opt=True): 2-d images")
         self.only_y_gamma = bool(only_y_gamma) and self.use_yuv          # smoe_test.py:43-44, smoe.py:725-729
         self.use_diff_center = bool(use_diff_center)
         self.overlap = int(overlap_of_batches)                            # smoe.py:244

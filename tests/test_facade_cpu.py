@@ -564,6 +564,21 @@ def test_fake_quantised_centre_offsets_through_the_facade(mode):
     assert np.abs(g.get_params()["musX"]).max() > 0 and g.get_losses()[-1][1] < g.get_losses()[0][1] * 1.5
 
 
+def test_shared_facade_with_the_ssim_loss_on_video():
+    from fake_engine import OracleSharedEngine
+    from steered_mixture_of_experts_amd.smoe import SharedSmoe
+    rng = np.random.default_rng(6)
+    g = np.stack(np.meshgrid(*[np.linspace(0, 1, n) for n in (16, 16, 6)], indexing="ij"), -1)
+    vid = np.clip(0.5 + 0.3 * np.sin(5 * g[..., :1] + 3 * g[..., 1:2] + 2 * g[..., 2:]) + 0.02 * rng.standard_normal((16, 16, 6, 1)),
+                  0, 1).astype(np.float32)
+    s = SharedSmoe(vid, train_inverse_cov=False, kernels_per_dim=[2, 2, 1], batch_size=[8, 8, 6], use_determinant=True,
+                   ssim_opt=True, engine_factory=OracleSharedEngine)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(0.01))
+    s.train(4, val_iter=2)
+    losses = [v for _, v in s.get_losses()]
+    assert 0.0 < losses[-1] < losses[0]
+
+
 def test_shared_facade_with_the_ssim_loss():
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import SharedSmoe

@@ -372,7 +372,10 @@ def test_shared_image_wide_records_follow_the_fit(kw):
 @pytest.mark.parametrize("shape,bshape,C,kpd,yuv,ov", [((64, 64), (16, 16), 1, [4, 4], False, 0),
                                                        ((64, 96), (32, 32), 3, [3, 5], True, 0),
                                                        ((96, 64), (32, 64), 1, [6, 4], False, 0),
-                                                       ((48, 40), (16, 8), 1, [12, 12], False, 3)])
+                                                       ((48, 40), (16, 8), 1, [12, 12], False, 3),
+                                                       # 3-d batches: the 11x11x11 window (smoe.py:999-1003)
+                                                       ((16, 16, 12), (8, 8, 6), 3, [2, 2, 2], True, 0),
+                                                       ((16, 24, 8), (8, 8, 8), 1, [2, 3, 1], False, 0)])
 def test_shared_ssim_loss(shape, bshape, C, kpd, yuv, ov):
     """ssim_opt in the shared-kernel mode: loss_pixel = 1 - SSIM of every batch (smoe.py:980-1011; with a halo the
     interior is cropped first, smoe.py:984-991), gradients accumulated over the batches."""
