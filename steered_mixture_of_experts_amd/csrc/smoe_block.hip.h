@@ -2187,6 +2187,26 @@ hipError_t launch_readmit_quant(const ReadmitArgs& a, const KernelConsts& kc, hi
 // ---------------------------------------------------------------------------
 // launchers + dispatch table
 // ---------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize sticks to the function: set it when a launch needs more than any earlier one
+// of this thread did (one process per GPU; the call costs microseconds of host time in front of every launch otherwise).
+inline hipError_t allow_lds(const void* kern, size_t bytes) {
+    struct Seen { const void* k; size_t b; int dev; };
+    static thread_local Seen seen[64];
+    static thread_local int nseen = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i].k == kern && seen[i].dev == dev) {
+            if (seen[i].b >= bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) seen[i].b = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && nseen < 64) seen[nseen++] = Seen{kern, bytes, dev};
+    return e;
+}
+
 template <int D, int C, int K, int G, int WAVES>
 hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     using T = Tile<D, C, K, G, WAVES>;
@@ -2208,7 +2228,7 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     size_t shm_all = shm;
     aa.desc_off = 0;
     if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
+    hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + nb - 1) / nb;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
@@ -2233,7 +2253,7 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     FwdArgs aa = a;
     aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
     const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
@@ -2257,7 +2277,7 @@ hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
     size_t shm_all = shm;
     aa.desc_off = 0;
     if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
+    hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
@@ -2274,7 +2294,7 @@ hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
     FwdArgs aa = a;
     aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
     const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
@@ -2295,7 +2315,7 @@ hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
     size_t shm_all = shm;
     aa.desc_off = 0;
     if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
+    hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
@@ -2312,7 +2332,7 @@ hipError_t launch_fwd_ic(const FwdArgs& a, hipStream_t st) {
     FwdArgs aa = a;
     aa.regt = ((a.N + G - 1) / G <= T::FWD_PXR) ? 1 : 0;
     const size_t shm = aa.regt ? sizeof(float) * (size_t)T::off_tgt(a.N, D - hl) : T::bytes(a.N, a.loss_w != nullptr, D - hl);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
@@ -2341,7 +2361,7 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
     size_t shm_all = shm;
     aa.desc_off = 0;
     if (T::wants_owner_post(a.N)) { aa.desc_off = (int)(shm / sizeof(float)); shm_all += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE; }
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_all);
+        hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
@@ -2360,7 +2380,7 @@ hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
         const bool q = a.kc.qmode >= 2;
         auto kern = q ? (a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, true, true> : forward_kernel<D, C, K, G, WAVES, true, true>)
                       : (a.kc.inverse_cov ? forward_kernel<D, C, K, G, WAVES, true, false, true> : forward_kernel<D, C, K, G, WAVES, true>);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
         FwdArgs aa = a;
@@ -2398,7 +2418,7 @@ int fit_occupancy(int N, bool has_lw, int hoist, bool pair) {
     }
     size_t shm = T::bytes(N, has_lw, D - hl);
     if (T::wants_owner_post(N)) shm += sizeof(float) * (size_t)T::NB * T::DESC_STRIDE;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return -1;
+    if (allow_lds(reinterpret_cast<const void*>(kern), shm) != hipSuccess) return -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, T::THREADS, shm) != hipSuccess) return -1;
     return nb * WAVES;       // resident wavefronts per CU
 }
