@@ -21,6 +21,7 @@ struct smoe_context {
     double* d_partials;  // workspace of smoe_reduce_scalars
     int force_g;
     const float* mus_grid;   // use_diff_center: kernel-grid centres [B,K,D] of the blocks the calls pass (smoe_set_center_grid), or null
+    mutable int big_g;   // lanes per block for blocks of more than 512 pixels (big_block_lanes; -1: not asked yet)
     int pair_occ;        // wavefronts per CU the 64-lane fit kernel reaches (-1: not asked yet)
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     smoe::KernelConsts kc;
@@ -137,11 +138,34 @@ bool variant_serves(const smoe::Variant& v, const smoe_context* h) {
 // Lanes per block by batch size (measured on 16x16 blocks, profiles/r02/bench_shapes.txt): many blocks -> 16 lanes per
 // block (4 blocks per wavefront: the per-iteration work outside the pixel loop is amortised over 16 pixels per lane);
 // few blocks -> more lanes per block, so that every SIMD of the 256 CUs has wavefronts to interleave.
-// Large blocks (>= 1024 pixels) always use a whole wavefront per block: 16 lanes would leave 64+ pixels per lane, and
-// with 64 lanes two trailing axes of a 16x16x4 block can be hoisted.
+// Large blocks (> 512 pixels): big_block_lanes -- 16 lanes would leave 64+ pixels per lane.
+// Blocks of more than 512 pixels: a whole wavefront per block -- unless that kernel's registers allow ONE wavefront per
+// SIMD only and the 32-lane kernel hoists as much: lone wavefronts either way, and two blocks per wavefront share the
+// per-iteration work outside the pixel loop (32x32 / K = 8 / RGB, 316 VGPRs: 76.9 -> 88.2 Gpx-it/s at 2 040 blocks;
+// 16x16x4 blocks stay on 64 lanes, where both trailing axes are hoisted: 202 vs 120).
+int big_block_lanes(const smoe_context* h) {
+    if (h->big_g > 0) return h->big_g;
+    int n = 0;
+    const smoe::Variant* v = smoe::variants(&n);
+    const smoe::Variant *v64 = nullptr, *v32 = nullptr;
+    for (int i = 0; i < n; ++i) {
+        if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels || !variant_serves(v[i], h)) continue;
+        if (v[i].lds_bytes(h->N, false, h->cfg.quantization_mode >= 2) > 160u * 1024u) continue;
+        if (v[i].G == 64) v64 = &v[i];
+        if (v[i].G == 32) v32 = &v[i];
+    }
+    int g = 64;
+    if (v64 && v32 && !h->cfg.ssim_opt && hoist_level(h, v32) >= hoist_level(h, v64) && hipSetDevice(h->cfg.device) == hipSuccess) {
+        const int occ = v64->fit_waves_per_cu(h->N, false, hoist_level(h, v64), false);
+        if (occ > 0 && occ < 8) g = 32;
+    }
+    h->big_g = g;
+    return g;
+}
+
 int wanted_lanes(const smoe_context* h, int num_blocks) {
     if (h->force_g) return h->force_g;
-    if (h->N > 512) return 64;
+    if (h->N > 512) return (num_blocks >= 1536) ? big_block_lanes(h) : 64;     // fewer: 32 lanes would leave SIMDs without a wavefront
     if (num_blocks >= 8192) return 16;      // 8 192 blocks: 276 (16 lanes) vs 213 (32) Gpx-it/s
     if (num_blocks >= 3072) return 32;      // 4 096 blocks: 208 (32) vs 177 (16) vs 157 (64); 2 048 blocks: 2 wavefronts per SIMD on 64 lanes win
     return 64;
@@ -258,6 +282,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->force_g = 0;
     h->force_pair = 0;
     h->pair_occ = -1;
+    h->big_g = -1;
     h->mus_grid = nullptr;
     h->d_coords = nullptr;
     h->d_probes = nullptr;
