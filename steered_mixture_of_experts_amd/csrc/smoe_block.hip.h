@@ -113,6 +113,9 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #ifndef SMOE_REGRED
 #define SMOE_REGRED 0
 #endif
+#ifndef SMOE_W2_SLOTS
+#define SMOE_W2_SLOTS 96       // fit_min_waves: triples with at least this many slots are bound to two wavefronts per SIMD on 64 lanes
+#endif
 #ifndef SMOE_NT_STORES
 #define SMOE_NT_STORES 1
 #endif
@@ -1223,8 +1226,20 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // phase.  Two workgroup barriers per iteration (totals handed over / parameters written).  A lone wavefront issues one
 // VALU instruction per ~5.6 cycles whatever its instruction-level parallelism (profiles/r02/ubench_valu.txt), two per
 // SIMD one per ~3.2: the second wavefront is nearly free.
+// Parameter-rich triples on the one-block-per-wavefront tiling: the kernel is told to stay within 256 VGPRs (two
+// wavefronts per SIMD).  Left alone the compiler takes ~320 (launch bounds of 128 threads allow 512), which makes 2 040
+// blocks two ROUNDS of lone wavefronts at 5.6 cycles per instruction; with the bound it parks ~60 loop-invariant values in
+// scratch (a handful of reloads per pixel step) and the two wavefronts share a SIMD: 32x32 / K = 8 / RGB 76.9 -> 102.4
+// Gpx-it/s, with train_inverse_cov 70 -> 94.  (Round 1 measured the same attribute as a loss, 62 -> 53: the kernel of that
+// round spilled inside the pixel loop.)  Not on the 32-lane tiling (1 020 wavefronts are lone anyway: 88 -> 60) and not on the smaller triples, whose
+// kernels are at or below 256 registers or run three wavefronts per SIMD.
+// (Margin-loss graph without mode-2/3 quantisation only: the quantised and SSIM variants spill twice as much under the
+// bound and lose -- mode 3: 54 -> 45, mode 2: 70 -> 61, SSIM 3.5 -> 2.5 Gpx-it/s; scripts/cfg3_variants.py.)
+template <int D, int C, int K, int G, bool SSIM, bool QUANT>
+constexpr int fit_min_waves() { return (G == 64 && !SSIM && !QUANT && Layout<D, C, K>::NSLOT >= SMOE_W2_SLOTS) ? 2 : 1; }
+
 template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false, bool IC = false, bool PAIR = false>
-__global__ void __launch_bounds__(WAVES * 64) fit_kernel(FitArgs a) {
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(fit_min_waves<D, C, K, G, SSIM, QUANT>()))) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
     static_assert(!PAIR || (G == 64 && WAVES == 2 && !SSIM && !QUANT), "PAIR: one block on the two wavefronts of a workgroup");
