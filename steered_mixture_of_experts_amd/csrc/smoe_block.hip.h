@@ -1232,7 +1232,10 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // scratch (a handful of reloads per pixel step) and the two wavefronts share a SIMD: 32x32 / K = 8 / RGB 76.9 -> 102.4
 // Gpx-it/s, with train_inverse_cov 70 -> 94.  (Round 1 measured the same attribute as a loss, 62 -> 53: the kernel of that
 // round spilled inside the pixel loop.)  Not on the 32-lane tiling (1 020 wavefronts are lone anyway: 88 -> 60) and not on the smaller triples, whose
-// kernels are at or below 256 registers or run three wavefronts per SIMD.
+// kernels are at or below 256 registers or run three wavefronts per SIMD.  (The headline kernel bound to FOUR wavefronts per
+// SIMD -- 128 VGPRs + 22 parked dwords -- changes nothing with four-wavefront workgroups, 385.3 vs 386.5 Gpx-it/s: 43 KB
+// of LDS hold three workgroups per CU whatever the registers; with two-wavefront workgroups, seven per CU, it LOSES, 384.5 ->
+// 363.8: that kernel is bound by VALU issue, and a fourth wavefront adds reloads, not issue slots.)
 // (Margin-loss graph without mode-2/3 quantisation only: the quantised and SSIM variants spill twice as much under the
 // bound and lose -- mode 3: 54 -> 45, mode 2: 70 -> 61, SSIM 3.5 -> 2.5 Gpx-it/s; scripts/cfg3_variants.py.)
 template <int D, int C, int K, int G, bool SSIM, bool QUANT>

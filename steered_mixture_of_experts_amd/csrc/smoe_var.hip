@@ -11,10 +11,12 @@
 
 namespace smoe {
 // wavefronts per workgroup of the 16-lane tiling: four while the block images of 16 blocks fit next to three more workgroups
+#ifndef SMOE_W16
 #if SMOE_D == 2 && SMOE_K * SMOE_C <= 12
 #define SMOE_W16 4
 #else
 #define SMOE_W16 2
+#endif
 #endif
 
 // host function (a namespace-scope table of host function pointers would also be emitted for the device)
