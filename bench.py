@@ -492,6 +492,9 @@ def worker(args):
         if ent and "fixed_bytes_per_block" in ent:
             out["roofline"]["traffic"] = int(B * (ent["fixed_bytes_per_block"] + ent["bytes_per_block_iter"] * ipl))
             out["roofline"]["traffic_source"] = ent.get("source")
+            if launch_ms == launch_ms and launch_ms > 0:
+                # what the HBM really carries: measured bytes per launch / kernel time, as a fraction of the same peak
+                out["roofline"]["measured_hbm_frac"] = round(out["roofline"]["traffic"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         # the real bound: VALU issue.  profiles/pmc.json holds SQ_INSTS_VALU per pixel-iteration of the variant (PMC pass);
         # rate = value x instructions / 64 lanes; floor = 2 cycles per wave64 instruction per SIMD-32.
         pm = load_profile_json("pmc.json").get(variant)
