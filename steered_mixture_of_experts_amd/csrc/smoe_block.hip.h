@@ -113,8 +113,16 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #ifndef SMOE_REGRED
 #define SMOE_REGRED 0
 #endif
+// fit_min_waves: triples with this many slots are bound to two wavefronts per SIMD on 64 lanes.  Window from the table
+// profiles/r02/bench_rich_triples.txt (2 040 blocks, bound vs unbound, Gpx-it/s): 32x32 RGB K=8 (130 slots) 102 vs 85,
+// 32x32 K=12 (122) 111 vs 80, 32x32 RGB K=9 (143) 84 vs 66, 16x16x4 K=8 (122) 141 vs 99, 16x16x4 RGB K=6 (140) 118 vs 84,
+// 32x32 RGB K=6 (98) 136 vs 134; above the window the parked values no longer fit beside the pixel loop:
+// 16x16x4 RGB K=8 (186 slots) 58 vs 66, 32x32 K=16 (162) 20 vs 54.
 #ifndef SMOE_W2_SLOTS
-#define SMOE_W2_SLOTS 96       // fit_min_waves: triples with at least this many slots are bound to two wavefronts per SIMD on 64 lanes
+#define SMOE_W2_SLOTS 96
+#endif
+#ifndef SMOE_W2_SLOTS_MAX
+#define SMOE_W2_SLOTS_MAX 150
 #endif
 #ifndef SMOE_NT_STORES
 #define SMOE_NT_STORES 1
@@ -1238,11 +1246,15 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // 363.8: that kernel is bound by VALU issue, and a fourth wavefront adds reloads, not issue slots.)
 // (Margin-loss graph without mode-2/3 quantisation only: the quantised and SSIM variants spill twice as much under the
 // bound and lose -- mode 3: 54 -> 45, mode 2: 70 -> 61, SSIM 3.5 -> 2.5 Gpx-it/s; scripts/cfg3_variants.py.)
-template <int D, int C, int K, int G, bool SSIM, bool QUANT>
-constexpr int fit_min_waves() { return (G == 64 && !SSIM && !QUANT && Layout<D, C, K>::NSLOT >= SMOE_W2_SLOTS) ? 2 : 1; }
+// Hoisting kernels only: without hoisting the same triples take 420-510 VGPRs, the bound would park ~200 dwords and the
+// kernel crawls (24x24 / K = 8 / RGB: 53.8 -> 16.7 Gpx-it/s); unbound, big_block_lanes sends those shapes to 32 lanes.
+template <int D, int C, int K, int G, int HL, bool SSIM, bool QUANT>
+constexpr int fit_min_waves() {
+    return (G == 64 && HL >= 1 && !SSIM && !QUANT && Layout<D, C, K>::NSLOT >= SMOE_W2_SLOTS && Layout<D, C, K>::NSLOT <= SMOE_W2_SLOTS_MAX) ? 2 : 1;
+}
 
 template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false, bool IC = false, bool PAIR = false>
-__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(fit_min_waves<D, C, K, G, SSIM, QUANT>()))) fit_kernel(FitArgs a) {
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(fit_min_waves<D, C, K, G, HL, SSIM, QUANT>()))) fit_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
     using T = Tile<D, C, K, G, WAVES>;
     static_assert(!PAIR || (G == 64 && WAVES == 2 && !SSIM && !QUANT), "PAIR: one block on the two wavefronts of a workgroup");
