@@ -1,0 +1,14 @@
+#!/bin/bash
+# large batches of the parameter-rich triples on the 16-lane tiling
+run() { python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 10 "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('%-10s C%d K%-2d B=%-6d %-22s %10.1f Mpx-it/s  ms/launch %.3f' % ('x'.join(map(str,d['config']['block_shape'])), d['config']['channels'], d['config']['kernels'], d['config']['blocks_per_gpu'], d['config']['kernel_variant'], d['value'], r['kernel_ms_per_launch']))"; }
+run --blocks 32768 --block-shape 16 16 --channels 1 --kernels-per-dim 3 4
+run --blocks 32768 --block-shape 16 16 --channels 3 --kernels-per-dim 2 3
+run --blocks 32768 --block-shape 16 16 --channels 3 --kernels-per-dim 2 4
+run --blocks 32768 --block-shape 16 16 --channels 3 --kernels-per-dim 3 3
+run --blocks 32768 --block-shape 8 8 4 --channels 3 --kernels-per-dim 2 2 1
+run --blocks 32768 --block-shape 8 8 4 --channels 1 --kernels-per-dim 2 3 1
+run --blocks 32768 --block-shape 8 8 4 --channels 1 --kernels-per-dim 2 2 2
+run --blocks 32768 --block-shape 8 8 4 --channels 3 --kernels-per-dim 1 3 2

@@ -121,6 +121,12 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #ifndef SMOE_W2_SLOTS
 #define SMOE_W2_SLOTS 96
 #endif
+// the same bound on the 16-lane hoisting kernels of the triples with 90..150 slots (large batches of small blocks with many
+// kernels: 32 768 blocks of 16x16 K=12 76 -> 112 Gpx-it/s, 8x8x4 K=6 104 -> 164, 8x8x4 RGB K=4 94 -> 111; none slower:
+// profiles/r02/bench_rich_triples.txt)
+#ifndef SMOE_W2_G16
+#define SMOE_W2_G16 1
+#endif
 #ifndef SMOE_W2_SLOTS_MAX
 #define SMOE_W2_SLOTS_MAX 150
 #endif
@@ -1250,7 +1256,8 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // kernel crawls (24x24 / K = 8 / RGB: 53.8 -> 16.7 Gpx-it/s); unbound, big_block_lanes sends those shapes to 32 lanes.
 template <int D, int C, int K, int G, int HL, bool SSIM, bool QUANT>
 constexpr int fit_min_waves() {
-    return (G == 64 && HL >= 1 && !SSIM && !QUANT && Layout<D, C, K>::NSLOT >= SMOE_W2_SLOTS && Layout<D, C, K>::NSLOT <= SMOE_W2_SLOTS_MAX) ? 2 : 1;
+    return ((G == 64 || (G == 16 && SMOE_W2_G16)) && HL >= 1 && !SSIM && !QUANT && Layout<D, C, K>::NSLOT >= ((G == 64) ? SMOE_W2_SLOTS : 90)
+            && Layout<D, C, K>::NSLOT <= SMOE_W2_SLOTS_MAX) ? 2 : 1;
 }
 
 template <int D, int C, int K, int G, int WAVES, int HL, bool SSIM = false, bool QUANT = false, bool IC = false, bool PAIR = false>
