@@ -197,6 +197,11 @@ def load_profile_json(name):
 
 
 def worker(args):
+    # stdout carries ONE JSON line.  Libraries write to file descriptor 1 behind Python's back (RCCL prints a version banner
+    # at init on this image): for the length of the run fd 1 points at stderr, the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     from steered_mixture_of_experts_amd import blocks as blk
@@ -545,7 +550,8 @@ def worker(args):
                                            "psnr_delta_db": round(gw - cw, 4),
                                            "median_block_psnr_delta_db": round(gwm - cwm, 4),
                                            "psnr_ok": bool(abs(gw - cw) <= 0.05 and abs(gwm - cwm) <= 0.05)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
