@@ -211,6 +211,8 @@ def worker(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SMOE_BENCH_SHARE_GPU") == "1":   # rehearsal of N ranks on a box with fewer GPUs (with --backend gloo)
+        local_rank %= max(1, torch.cuda.device_count())
     on_gpu = not args.engine_factory
     if args.engine_factory:                          # test double (CPU); see parse_args
         mod, attr = args.engine_factory.split(":")
