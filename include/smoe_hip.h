@@ -133,6 +133,9 @@ int smoe_is_supported(int32_t dim, int32_t channels, int32_t kernels);
  * count with kernels of prior 0: `bool_mask = kernel_list & pis > 0` (smoe.py:480,738) takes them out of the graph,
  * their gradients are 0 and ApplyAdam leaves a variable with zero slots and zero gradient where it is. */
 int smoe_padded_kernels(int32_t dim, int32_t channels, int32_t kernels);
+/* The same over the triples built with EVERY graph variant (ssim_opt, quantization_mode 2 / 3; the lines marked FULL in
+ * csrc/smoe_variants.def): what a caller pads to when its graph needs one of those kernels. */
+int smoe_padded_kernels_full(int32_t dim, int32_t channels, int32_t kernels);
 
 /* Copy the device-resident per-pixel coordinates [d][N] (fp32) to a HOST buffer. */
 int smoe_get_coords(smoe_handle h, float* host_out);
@@ -196,6 +199,15 @@ int smoe_set_center_grid(smoe_handle h, const float* grid);
  * wavefronts of a workgroup in smoe_fit (the automatic choice for at most 1 024 blocks of the plain margin-loss graph;
  * other graphs and the evaluation run the plain 64-lane kernel).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
+
+/* Partition invariance.  The reference walks ALL blocks of an image in one host loop (smoe.py:1643-1702): a block's
+ * result does not depend on how many other blocks the pass holds.  Here the lanes-per-block tiling -- and with it the
+ * order in which a block's per-pixel gradient terms are summed -- is chosen from the number of blocks, so that a shard
+ * of an image (one of R ranks, smoe_fit called with num_blocks = B / R) would round differently from the whole image.
+ * total_blocks > 0: every later call of this handle chooses its kernels as if it held total_blocks blocks (the block
+ * count of the WHOLE job the calls are shards of), whatever num_blocks it is given: per-block results are then
+ * bit-identical for every split of the job into calls / ranks.  0 (the default) = choose from each call's num_blocks. */
+int smoe_set_total_blocks(smoe_handle h, int64_t total_blocks);
 
 /* ---------------------------------------------------------------------------------------------
  * Shared-kernel image mode: the reference's whole-image fit.  ONE global set of K

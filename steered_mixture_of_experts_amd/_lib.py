@@ -26,7 +26,7 @@ EXPORTS = (
     "smoe_shared_create", "smoe_shared_destroy", "smoe_shared_num_batches", "smoe_shared_list_words",
     "smoe_shared_forward", "smoe_shared_accumulate", "smoe_shared_apply", "smoe_shared_grad_buffer",
     "smoe_shared_fit", "smoe_shared_update_kernel_list", "smoe_shared_set_loss_weights",
-    "smoe_set_center_grid", "smoe_shared_set_center_grid",
+    "smoe_set_center_grid", "smoe_shared_set_center_grid", "smoe_set_total_blocks", "smoe_padded_kernels_full",
 )
 
 
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     lib.smoe_create.argtypes = [C.POINTER(vp), C.POINTER(SmoeConfig)]
     lib.smoe_destroy.argtypes = [vp]
     lib.smoe_is_supported.argtypes = [i32, i32, i32]
+    lib.smoe_padded_kernels.argtypes = [i32, i32, i32]
+    lib.smoe_padded_kernels_full.argtypes = [i32, i32, i32]
     lib.smoe_get_coords.argtypes = [vp, fp]
     lib.smoe_forward.argtypes = [vp, i32, fp, fp, C.POINTER(SmoeParams), fp, fp, fp, fp, fp, fp, i32, vp]
     lib.smoe_fit.argtypes = [vp, i32, fp, fp, C.POINTER(SmoeParams), C.POINTER(SmoeAdamState), i32,
@@ -105,6 +107,7 @@ def load() -> C.CDLL:
     lib.smoe_fit_variant.restype = C.c_char_p
     lib.smoe_fit_occupancy.argtypes = [vp, i32]
     lib.smoe_set_tiling.argtypes = [vp, i32]
+    lib.smoe_set_total_blocks.argtypes = [vp, C.c_int64]
     lib.smoe_last_error.restype = C.c_char_p
     lib.smoe_shared_create.argtypes = [C.POINTER(vp), C.POINTER(SmoeSharedConfig)]
     lib.smoe_shared_destroy.argtypes = [vp]

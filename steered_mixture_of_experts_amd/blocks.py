@@ -72,7 +72,8 @@ def blocks_to_image(blocks: np.ndarray, domain_shape: Sequence[int], block_shape
 def to_planar(blocks: np.ndarray) -> np.ndarray:
     """(B, *block_shape, C) -> (B, C, N): the C-ABI target layout (include/smoe_hip.h)."""
     B, C = blocks.shape[0], blocks.shape[-1]
-    return np.ascontiguousarray(blocks.reshape(B, -1, C).transpose(0, 2, 1))
+    N = int(np.prod(blocks.shape[1:-1]))           # explicit: a rank may hold no blocks at all (B = 0)
+    return np.ascontiguousarray(blocks.reshape(B, N, C).transpose(0, 2, 1))
 
 
 def from_planar(arr: np.ndarray, block_shape: Sequence[int]) -> np.ndarray:

@@ -502,7 +502,11 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         float eg = e[k][0] * Gc[0];
 #pragma unroll
         for (int c = 1; c < C; ++c) eg = fmaf(e[k][c], Gc[c], eg);
-        const float u = fmaf(o.wt[k], eg, -(w[k] * dot));
+        float u = fmaf(o.wt[k], eg, -(w[k] * dot));
+        // One kernel per block: w = g / g = 1 and u = e.G - G.y vanishes identically (the restatement's IEEE division gives
+        // exactly 0); with the hardware reciprocal a rounding residue would be left, which Adam normalises into a step of
+        // the size of the learning rate on pis / musX / A.  Only on the 1e-11 floor of the normaliser the gate still moves.
+        if constexpr (K == 1) u = (S > 10e-12f) ? 0.0f : u;
         float* a = acc + k * Lt::PK;
         a[Lt::O_PI] += u;
         if (IC) {
@@ -1249,7 +1253,8 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
 // blocks two ROUNDS of lone wavefronts at 5.6 cycles per instruction; with the bound it parks ~60 loop-invariant values in
 // scratch (a handful of reloads per pixel step) and the two wavefronts share a SIMD: 32x32 / K = 8 / RGB 76.9 -> 102.4
 // Gpx-it/s, with train_inverse_cov 70 -> 94.  (Round 1 measured the same attribute as a loss, 62 -> 53: the kernel of that
-// round spilled inside the pixel loop.)  Not on the 32-lane tiling (1 020 wavefronts are lone anyway: 88 -> 60) and not on the smaller triples, whose
+// round spilled inside the pixel loop.)  On the 32-lane tiling of these 64-lane-sized blocks it loses (1 020 wavefronts are lone anyway: 88 -> 60; the
+// 32-lane bound SMOE_W2_G32 is for the mid-size batches of SMALL blocks) and it is not applied to the smaller triples, whose
 // kernels are at or below 256 registers or run three wavefronts per SIMD.  (The headline kernel bound to FOUR wavefronts per
 // SIMD -- 128 VGPRs + 22 parked dwords -- changes nothing with four-wavefront workgroups, 385.3 vs 386.5 Gpx-it/s: 43 KB
 // of LDS hold three workgroups per CU whatever the registers; with two-wavefront workgroups, seven per CU, it LOSES, 384.5 ->

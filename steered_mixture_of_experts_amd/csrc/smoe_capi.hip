@@ -24,6 +24,7 @@ struct smoe_context {
     mutable int big_g;   // lanes per block for blocks of more than 512 pixels (big_block_lanes; -1: not asked yet)
     int pair_occ;        // wavefronts per CU the 64-lane fit kernel reaches (-1: not asked yet)
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
+    long long total_blocks;   // smoe_set_total_blocks: block count of the whole job the calls are shards of (0: each call's own)
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
 };
@@ -163,6 +164,13 @@ int big_block_lanes(const smoe_context* h) {
     return g;
 }
 
+// The block count the kernel choice is made from: the whole job's when the caller declared it (smoe_set_total_blocks:
+// the tiling fixes the summation order of a block's gradient terms, so every shard of a job must take the same one).
+int choice_blocks(const smoe_context* h, int num_blocks) {
+    if (h->total_blocks <= 0) return num_blocks;
+    return (h->total_blocks > 0x7fffffffLL) ? 0x7fffffff : (int)h->total_blocks;
+}
+
 int wanted_lanes(const smoe_context* h, int num_blocks) {
     if (h->force_g) return h->force_g;
     if (h->N > 512) return (num_blocks >= 1536) ? big_block_lanes(h) : 64;     // fewer: 32 lanes would leave SIMDs without a wavefront
@@ -180,7 +188,7 @@ bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
     if (v->G != 64 || v->W != 2 || h->N < 128) return false;
     if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov) return false;
     if (h->force_pair) return h->force_pair > 0;
-    if (num_blocks > PAIR_MAX_BLOCKS) return false;
+    if (choice_blocks(h, num_blocks) > PAIR_MAX_BLOCKS) return false;
     if (h->pair_occ < 0) h->pair_occ = v->fit_waves_per_cu(h->N, false, hoist_level(h, v), true);   // of the PAIR kernel itself
     return h->pair_occ >= 8;                                   // two wavefronts per SIMD can be resident together
 }
@@ -188,7 +196,7 @@ bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
-    const int want = wanted_lanes(h, num_blocks);
+    const int want = wanted_lanes(h, choice_blocks(h, num_blocks));
     const smoe::Variant* fallback = nullptr;
     int fallback_dist = 1 << 30;
     const bool hq = h->cfg.quantization_mode >= 2;     // the mode-2/3 fit kernels keep a quantised parameter image in LDS
@@ -232,6 +240,15 @@ int smoe_padded_kernels(int32_t dim, int32_t channels, int32_t kernels) {
     const smoe::Variant* v = smoe::variants(&n);
     for (int i = 0; i < n; ++i)
         if (v[i].D == dim && v[i].C == channels && v[i].K >= kernels && (best < 0 || v[i].K < best)) best = v[i].K;
+    return best;
+}
+
+int smoe_padded_kernels_full(int32_t dim, int32_t channels, int32_t kernels) {
+    int n = 0, best = -1;
+    const smoe::Variant* v = smoe::variants(&n);
+    for (int i = 0; i < n; ++i)
+        if (v[i].D == dim && v[i].C == channels && v[i].K >= kernels && v[i].fit_ssim != nullptr && v[i].fit_quant != nullptr &&
+            (best < 0 || v[i].K < best)) best = v[i].K;
     return best;
 }
 
@@ -281,6 +298,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->N = (int)N;
     h->force_g = 0;
     h->force_pair = 0;
+    h->total_blocks = 0;
     h->pair_occ = -1;
     h->big_g = -1;
     h->mus_grid = nullptr;
@@ -415,6 +433,13 @@ int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     // train_inverse_cov off; other graphs run the plain 64-lane kernel)
     h->force_g = (lanes_per_block == 128) ? 64 : lanes_per_block;
     h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0) ? 0 : -1);
+    return SMOE_OK;
+}
+
+int smoe_set_total_blocks(smoe_handle h, int64_t total_blocks) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_total_blocks: null handle");
+    if (total_blocks < 0) return fail(SMOE_ERR_INVALID, "smoe_set_total_blocks: negative block count");
+    h->total_blocks = (long long)total_blocks;
     return SMOE_OK;
 }
 

@@ -181,6 +181,12 @@ class BlockEngine:
     def set_tiling(self, lanes_per_block: int):
         _lib.check(self.lib.smoe_set_tiling(self._h, lanes_per_block))
 
+    def set_total_blocks(self, total_blocks: int):
+        """Block count of the WHOLE job the calls of this engine are shards of (0 = each call's own count): the kernel
+        tiling -- and with it the summation order inside a block -- is then the same for every split of the job over
+        calls / ranks, so per-block results are bit-identical (include/smoe_hip.h: smoe_set_total_blocks)."""
+        _lib.check(self.lib.smoe_set_total_blocks(self._h, int(total_blocks)))
+
     def set_center_grid(self, grid: Optional[torch.Tensor]):
         """use_diff_center with quantization_mode 2 / 3: the kernel-grid centres [B, K, d] (float32, on the device, laid
         out like musX) the trained offsets are relative to, or None to clear.  The engine keeps a reference."""

@@ -12,11 +12,15 @@ returns.  All blocks are fitted by ONE kernel launch per chunk of iterations ins
 
 Also built: the shared-kernel image mode with batch overlap (``SharedSmoe``), the SSIM loss
 (2-d blocks), the parameter quantiser and quantisation-aware fitting (``quantization_mode`` 1-3, ``quantize_pis``),
-``train_inverse_cov``, ``radial_as``, ``use_diff_center``.  Any kernel grid is accepted: a kernel count without its own
-kernel instantiation is padded to the next instantiated one with prior-zero kernels, which the graph drops
-(``bool_mask = kernel_list & pis > 0``, smoe.py:480,738).  Not rebuilt (SURVEY section 2 "OUT OF SCOPE"): support
-vectors, motion models, kernel adding, pixel sub-sampling; passing those options raises NotImplementedError instead
-of silently doing something else.
+``train_inverse_cov``, ``radial_as``, ``use_diff_center``, pixel sub-sampling (``sampling_percentage``).  Any kernel grid
+is accepted: a kernel count without its own kernel instantiation is padded to the next instantiated one with prior-zero
+kernels, which the graph drops (``bool_mask = kernel_list & pis > 0``, smoe.py:480,738).  Not rebuilt (SURVEY section 2
+"OUT OF SCOPE"): support vectors, motion models, kernel adding; passing those options raises NotImplementedError
+instead of silently doing something else.
+
+Partition invariance: the engine is told the block count of the WHOLE image (``set_total_blocks``), so a rank that
+holds a shard of the blocks runs the kernels the whole image would run and every block's result is bit-identical for
+any number of ranks -- the reference has one host loop over all blocks (smoe.py:1643-1702).
 """
 from __future__ import annotations
 
@@ -48,13 +52,16 @@ def _default_engine_factory(cfg: EngineConfig, device):
     return BlockEngine(cfg, device)
 
 
-def _default_padded_kernels(dim: int, channels: int, kernels: int) -> int:
-    """Smallest instantiated kernel count >= kernels (include/smoe_hip.h: smoe_padded_kernels)."""
+def _default_padded_kernels(dim: int, channels: int, kernels: int, need_full: bool = False) -> int:
+    """Smallest instantiated kernel count >= kernels (include/smoe_hip.h: smoe_padded_kernels); need_full: among the
+    triples built with the SSIM / quantization_mode 2, 3 kernels (smoe_padded_kernels_full)."""
     from . import _lib
-    kp = int(_lib.load().smoe_padded_kernels(dim, channels, kernels))
+    lib = _lib.load()
+    kp = int(lib.smoe_padded_kernels_full(dim, channels, kernels) if need_full else lib.smoe_padded_kernels(dim, channels, kernels))
     if kp < 0:
         raise NotImplementedError(f"no per-block kernel is instantiated for {kernels} or more kernels per block with "
-                                  f"(dim={dim}, channels={channels}); add the triple to csrc/smoe_variants.def")
+                                  f"(dim={dim}, channels={channels}{', every graph variant' if need_full else ''}); "
+                                  "add the triple to csrc/smoe_variants.def")
     return kp
 
 
@@ -211,7 +218,13 @@ class Smoe:
         self.kernels = K
         # kernel count of the engine: K itself when a kernel is instantiated for it, else the next instantiated count
         pk = getattr(engine_factory, "padded_kernels", None) if engine_factory is not None else _default_padded_kernels
-        self._kp = K if pk is None else int(pk(d, C, K))
+        need_full = bool(ssim_opt) or int(quantization_mode) >= 2      # graphs only the FULL triples are built for
+        if pk is None:
+            self._kp = K
+        elif engine_factory is None:
+            self._kp = int(pk(d, C, K, need_full))
+        else:
+            self._kp = int(pk(d, C, K))
         p0 = _pad_kernels(p0, self._kp)
         # use_diff_center (smoe.py:390-394,746-747): the trained variable is the OFFSET from the kernel
         # grid (initialised to zero); the engine works on grid + offset, the getters subtract the grid.
@@ -248,7 +261,9 @@ class Smoe:
         self._diverged = torch.zeros((self.B,), dtype=torch.int32, device=dev)
         self._loss0 = None
         self._best_loss_blocks = None
-        self._sampl_prob = None              # per-pixel sampling probabilities of the last reconstruction pass (smoe.py:906-907)
+        # per-pixel sampling probabilities of the sub-sampled passes: uniform until the first reconstruction pass replaces
+        # them by the error-proportional ones (smoe.py:270-272,906-907,1768-1769)
+        self._sampl_prob = torch.full((self.B, N), 1.0 / N, dtype=torch.float32, device=dev)
 
         # -- histories (smoe.py:183-199) -------------------------------------------------
         self.losses, self.mses, self.num_pis, self.num_svs = [], [], [], []
@@ -288,6 +303,9 @@ class Smoe:
                 self._engine.close()
             self._engine = self._engine_factory(cfg, self._device)
             self._engine_key = key
+            # the kernels (= the summation order inside a block) are chosen for the whole image, not for this rank's shard
+            if hasattr(self._engine, "set_total_blocks"):
+                self._engine.set_total_blocks(self.num_blocks)
             self._hand_over_center_grid()
 
     def _hand_over_center_grid(self):
@@ -389,13 +407,12 @@ class Smoe:
 
     def _sample_pixels(self, sampling_percentage):
         """Pixel sub-sampling (smoe.py:1664-1667): every block trains on round(N * p / 100) pixels drawn without
-        replacement with the error-proportional probabilities of the last reconstruction pass (smoe.py:906-907).  The
+        replacement with the error-proportional probabilities of the last reconstruction pass (smoe.py:906-907; uniform
+        before the first one, smoe.py:270-272).  The
         reference feeds only the drawn pixels; here they get the loss weight N / n (the others 0), which gives the same
         loss and the same gradients -- `mean` over the n drawn pixels.  Draws: exponential-race keys (the successive-
         sampling law of numpy's `choice(replace=False, p=...)`, another random stream).  Deviation: the kernel list is
         pruned by the influence over ALL pixels of the block (a superset of the reference's list)."""
-        if getattr(self, "_sampl_prob", None) is None:
-            self.run_batched(train=False, update_reconstruction=True)
         B, N = self._sampl_prob.shape
         n = max(1, int(round(N * sampling_percentage / 100.0)))
         gen = getattr(self, "_sample_gen", None)

@@ -165,6 +165,9 @@ class OracleEngine:
     def fit_variant(self, B):
         return "oracle"
 
+    def set_total_blocks(self, total_blocks):
+        self.total_blocks = int(total_blocks)       # the oracle has one summation order: nothing to choose
+
 
 class OracleSharedEngine:
     """Test double of ``SharedEngine`` on the numpy oracle (shared-kernel mode), torch CPU tensors."""

@@ -47,9 +47,22 @@ def test_strong_scaling_splits_one_image():
     assert abs(one["final_psnr_db"] - two["final_psnr_db"]) < 1e-6
 
 
+def test_four_ranks_one_of_them_without_blocks():
+    """B < ranks: 3 blocks over 4 ranks -- the last rank owns none, runs no kernel and still takes part
+    in every collective; the line carries one kernel variant per rank."""
+    one = _run(["--gpus", "1", "--scaling", "strong", "--image", "16", "48"])
+    four = _run(["--gpus", "4", "--scaling", "strong", "--image", "16", "48"])
+    assert four["n_gpus"] == 4 and four["rccl_ranks"] == 4 and len(four["per_rank_ms"]) == 4
+    assert four["config"]["total_blocks"] == 3 and four["config"]["blocks_rank0"] == 1
+    assert len(four["config"]["kernel_variant_per_rank"]) == 4 and "(0 blocks)" in four["config"]["kernel_variant_per_rank"][3]
+    assert abs(one["final_psnr_db"] - four["final_psnr_db"]) < 1e-6
+    assert one["state_digest"] == four["state_digest"]           # every block bit-identical whatever the split
+
+
 def test_short_timed_region_is_repeated_from_cloned_state():
     d = _run(["--gpus", "1", "--blocks", "4"])
-    assert d["config"]["reps"] >= 3 and len(d["config"]["timed_s_each_rep"]) == d["config"]["reps"]
+    assert d["config"]["reps"] >= 3 and len(d["config"]["timed_s_each_rep"]) == min(12, d["config"]["reps"])
+    assert d["config"]["timed_region_s_total"] >= 0.45 or d["config"]["reps"] == 2000       # an externally visible timed region
     once = _run(["--gpus", "1", "--blocks", "4", "--no-reps"])
     assert once["config"]["reps"] == 1
     assert abs(once["final_psnr_db"] - d["final_psnr_db"]) < 1e-9      # every repetition replays the same K steps

@@ -789,6 +789,31 @@ def test_pixel_sub_sampling_is_the_reference_subset_fit():
     assert s.get_iter() == 6 and s.get_losses()[-1][1] < l0 * 1.05
 
 
+def test_sub_sampled_training_pass_as_the_first_call_with_a_regulariser():
+    """run_batched(train=True, sampling_percentage < 100, pis_l1 != 0) as the FIRST call.  The sampling
+    probabilities start uniform (smoe.py:270-272), so no evaluation pass is nested into the training pass: the engine built
+    for (pis_l1, u_l1) stays the one that runs, and the kernel lists are pruned by that pass alone."""
+    img = _image(32, 32, seed=5)
+    s = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine)
+    assert np.allclose(s._sampl_prob.numpy(), 1.0 / 256)
+    s.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+    p0 = s.get_params()
+    loss, mse, num_pi, _ = s.run_batched(pis_l1=0.1, u_l1=0.01, train=True, sampling_percentage=50)
+    eng = s._engine
+    assert eng.cfg.pis_l1 == pytest.approx(0.1) and eng.cfg.u_l1 == pytest.approx(0.01)
+    assert np.isfinite(loss) and np.isfinite(mse) and num_pi == 16
+    assert np.allclose(s._sampl_prob.numpy(), 1.0 / 256)          # a training pass does not touch them (smoe.py:1768)
+    p1 = s.get_params()
+    assert not np.array_equal(p0["nu_e"], p1["nu_e"])             # the Adam step happened
+    # the l1 terms are part of the reported loss: the same pass without them is smaller by pis_l1 sum(pi)/K0 + u_l1 sum(diag A)
+    s2 = Smoe(img, train_inverse_cov=False, kernels_per_dim=[2, 2], batch_size=[16, 16], use_determinant=True, engine_factory=OracleEngine)
+    s2.set_optimizer(Adam(1e-3), Adam(1e-5), Adam(1e-2))
+    s2._sample_gen = None
+    l_reg = s2.run_batched(pis_l1=0.1, u_l1=0.01, train=False)[0]
+    l_plain = s2.run_batched(train=False)[0]
+    assert l_reg - l_plain == pytest.approx(0.1 * 1.0 / 4 + 0.01 * 4 * 2 * 6.0, rel=1e-4)   # per block: sum(pi) = 1, K0 = 4, A = 6 I
+
+
 def test_ragged_image_mse_counts_the_image_pixels_only():
     """on an image that is not a multiple of the block the reported MSE of a reconstruction pass equals the
     MSE of the cropped reconstruction (what get_psnr() reports), not that of the padded tiling."""

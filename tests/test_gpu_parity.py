@@ -203,11 +203,26 @@ def test_one_step_parity(case, tiling):
     edge = ((np.abs(ref64["y"]) < 1e-6) | (np.abs(ref64["y"] - 1) < 1e-6)).any(axis=(1, 2))
     clean = ~(tie | edge)
     assert clean.sum() >= (3 * B) // 4
-    # the fit kernel hoists lane-constant terms, the forward kernel (which produced `recon`) does not: a pixel on a
-    # quantiser tie may land one LSB apart in the two kernels, which moves that block's loss / SSE by ~1e-3 relative
+    # `recon` came from the evaluation kernel.  That it IS the fit kernel's own lattice is checked, not assumed: a fit launch
+    # with every learning rate 0 (no update) reports the loss / SSE of its own pass over the same parameters, and a single
+    # pixel one LSB apart would move a block's SSE by >= 1e-4 relative.  With the lattices equal, EVERY tie-free block has to
+    # meet the single-pass tolerance (was 85 % of them).
+    eng0 = _engine(shape, C, K, use_yuv=yuv, lr_expert=0.0, lr_pis=0.0, lr_steer=0.0)
+    eng0.set_tiling(tiling)
+    dp0 = _to_dev(p)
+    st0 = eng0.new_adam_state(dp0)
+    act0 = act.clone()
+    l_fit0, s_fit0 = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    eng0.fit(T, dp0, st0, act0, 1, loss_out=l_fit0, sse_out=s_fit0)
+    torch.cuda.synchronize()
+    for k in dp0:
+        assert torch.equal(dp0[k], dp[k]), k                      # zero learning rates: nothing moved
+    eng0.close()
+    same_lattice = _close(s_fit0.cpu().numpy(), fw["sse"].cpu().numpy(), rtol=2e-6, atol=1e-9)
+    assert same_lattice.all(), np.flatnonzero(~same_lattice)
+    assert _close(l_fit0.cpu().numpy(), fw["loss"].cpu().numpy(), rtol=2e-6, atol=1e-12).all()
     lc, sc = _close(loss.cpu().numpy()[clean], ref["loss"][clean], rtol=2e-5), _close(sse.cpu().numpy()[clean], ref["sse"][clean], rtol=2e-5)
-    assert lc.mean() >= 0.85 and sc.mean() >= 0.85
-    assert np.abs(sse.cpu().numpy()[clean] / ref["sse"][clean] - 1).max() < 5e-3
+    assert lc.all() and sc.all(), (np.flatnonzero(~lc), np.flatnonzero(~sc))
     m = _to_host(state.m)
     got = _to_host(dp)
     for name in o.PARAM_NAMES:
@@ -219,7 +234,12 @@ def test_one_step_parity(case, tiling):
         err = np.abs(g_got - g_ref).max() / scale
         assert err < 2e-5, (name, err)
         if K == 1 and name in ("pis", "musX", "A_diagonal", "A_corr"):
-            continue        # identically zero gradients: Adam turns the rounding residue (< 2e-5 of the expert scale) into a step
+            # one kernel per block: w = 1, these gradients vanish identically.  The kernel returns exact zeros (not the
+            # rounding residue of its hardware reciprocal, which Adam would normalise into a step of the size of the learning
+            # rate): slots and parameters stay where they were  
+            assert not m[name][clean].any(), name
+            assert np.array_equal(got[name][clean], p[name][clean]), name
+            continue
         perr = np.abs(got[name][clean] - p_ref[name][clean])
         # first TF1-Adam step: delta = lr*g/(|g| + eps*sqrt(1-b1)... ) = lr*g/(|g| + 3.16e-7):
         # an element's sensitivity to gradient noise dg is lr*e/(|g|+e)^2 with e = 1e-8/sqrt(1e-3)
@@ -229,6 +249,82 @@ def test_one_step_parity(case, tiling):
         tol = 1e-6 * (np.abs(p_ref[name][clean]) + 1.0) + 2e-5 * lr + lr * (4e-6 * scale) * e / (gabs + e) ** 2
         assert (perr <= tol).all(), (name, (perr / tol).max())
     eng.close()
+
+
+def test_cfg1_single_block_forward_and_200_iterations():
+    """BASELINE configs[0] on the HIP path: ONE 16x16 grayscale block, K = 4, 200 Adam iterations (B = 1: one workgroup,
+    the block on both of its wavefronts, 255 idle CUs; the tail-block path of every loader).  Six different blocks, each
+    run alone.  Evaluation pass against the restatement; the 200-iteration fit at the CLI defaults inside the restatement's
+    own fp32-vs-fp64 floor; with a well-conditioned steering step (lr_mult 10) within 0.05 dB and parameter-close."""
+    shape, C, kpd, K, N = (16, 16), 1, [2, 2], 4, 256
+    coords = o.block_coords(shape)
+    ps = lambda sse: float(-10 * np.log10(max(float(sse), 1e-12) / (N * C)))
+    d_gpu, d_floor, gentle = [], [], []
+    for seed in range(6):
+        b = synthetic_blocks(1, shape, C, 20260500 + seed)
+        tgt = b.reshape(1, -1, C)
+        p = o.init_params(b, kpd)
+        T = _planar(tgt)
+        cfg = o.OracleConfig(block_shape=shape, channels=C, kernels=K, quantize_pis=True)
+        eng = _engine(shape, C, K, quantize_pis=True)
+        assert eng.fit_variant(1).endswith("_g64w2")
+        # evaluation of the single block
+        dp = _to_dev(p)
+        act = torch.full((1,), 15, dtype=torch.int32, device="cuda")
+        out = eng.forward(T, dp, act, want_recon=True, want_argmax=True, want_gate=True)
+        ref = o.forward(p, tgt, coords, np.ones((1, K), bool), cfg, None, np.float32)
+        ref64 = o.forward(p, tgt, coords, np.ones((1, K), bool), cfg, None, np.float64)
+        recon = np.transpose(out["recon"].cpu().numpy(), (0, 2, 1))
+        frac = (np.clip(ref64["y"], 0, 1) * 255 + 0.5) % 1.0
+        tie = (frac < 2e-4) | (frac > 1 - 2e-4)
+        assert (np.abs(recon - ref["recon"])[~tie] < 1e-7).all() and (np.abs(recon - ref["recon"]) <= 1.0001 / 255).all()
+        refq = o.forward(p, tgt, coords, np.ones((1, K), bool), cfg, None, np.float32, q_override=recon)
+        assert _close(out["loss"].cpu().numpy(), refq["loss"], rtol=2e-5).all() and _close(out["sse"].cpu().numpy(), refq["sse"], rtol=2e-5).all()
+        assert _close(out["gate_w"].cpu().numpy(), ref["wt"]).all() or (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any()
+        assert np.array_equal(_bits_to_mask(act.cpu().numpy().view(np.uint32), K), ref["active_new"]) or (np.abs(ref64["w"] - 0.5 / 256) < 1e-6).any()
+        # the whole fit, CLI defaults (lr_steer = 1.0): 200 iterations in two launches with the readmission in between
+        st = eng.new_adam_state(dp)
+        f0 = eng.forward(T, dp, act, want_recon=False)
+        for _ in range(2):
+            eng.fit(T, dp, st, act, 100, loss0=f0["loss"])
+            eng.update_kernel_list(dp, act)
+        g = eng.forward(T, dp, act, want_recon=False)
+        torch.cuda.synchronize()
+        assert st.step == 200 and np.isfinite(g["sse"].cpu().numpy()).all()
+        p32, _, i32 = o.fit(p, tgt, coords, cfg, 200, val_iter=100, dtype=np.float32)
+        p64, _, i64 = o.fit(p, tgt, coords, cfg, 200, val_iter=100, dtype=np.float64)
+        a = ps(o.forward(p32, tgt, coords, i32["active"], cfg, None, np.float32)["sse"][0])
+        c = ps(o.forward(p64, tgt, coords, i64["active"], cfg, None, np.float64)["sse"][0])
+        d_gpu.append(abs(ps(g["sse"][0].item()) - a))
+        d_floor.append(abs(a - c))
+        eng.close()
+        # well-conditioned steering step: the regime in which a trajectory is reproducible (DESIGN section 5)
+        cfg_g = o.OracleConfig(block_shape=shape, channels=C, kernels=K, quantize_pis=True, lr_steer=1e-2)
+        eng = _engine(shape, C, K, quantize_pis=True, lr_steer=1e-2)
+        dp = _to_dev(p)
+        act = torch.full((1,), 15, dtype=torch.int32, device="cuda")
+        st = eng.new_adam_state(dp)
+        f0 = eng.forward(T, dp, act, want_recon=False)
+        for _ in range(2):
+            eng.fit(T, dp, st, act, 100, loss0=f0["loss"])
+            eng.update_kernel_list(dp, act)
+        g = eng.forward(T, dp, act, want_recon=False)
+        q32, _, j32 = o.fit(p, tgt, coords, cfg_g, 200, val_iter=100, dtype=np.float32)
+        q64, _, j64 = o.fit(p, tgt, coords, cfg_g, 200, val_iter=100, dtype=np.float64)
+        a = ps(o.forward(q32, tgt, coords, j32["active"], cfg_g, None, np.float32)["sse"][0])
+        c = ps(o.forward(q64, tgt, coords, j64["active"], cfg_g, None, np.float64)["sse"][0])
+        gentle.append((abs(ps(g["sse"][0].item()) - a), abs(a - c)))
+        got = _to_host(dp)
+        for name in ("nu_e", "musX", "pis"):
+            assert np.abs(got[name] - q32[name]).max() <= 3 * np.abs(q32[name] - q64[name]).max() + 1e-3 * (np.abs(q32[name]).max() + 1), (seed, name)
+        eng.close()
+    # CLI defaults: chaotic (A steps by ~1 per iteration through an 8-bit quantiser) -- judged against the restatement's
+    # own fp32-vs-fp64 spread over the six blocks
+    assert np.median(d_gpu) <= 1.5 * np.median(d_floor) + 0.05, (d_gpu, d_floor)
+    assert max(d_gpu) <= 2.0 * max(d_floor) + 0.5, (d_gpu, d_floor)
+    # gentle steering step: the contract's 0.05 dB per block (or inside the restatement's own spread where that is larger)
+    for dg, df in gentle:
+        assert dg <= max(0.05, 2 * df), gentle
 
 
 def test_short_trajectory_vs_sensitivity_floor():
