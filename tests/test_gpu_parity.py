@@ -216,7 +216,7 @@ def test_one_step_parity(case, tiling):
     eng0.fit(T, dp0, st0, act0, 1, loss_out=l_fit0, sse_out=s_fit0)
     torch.cuda.synchronize()
     for k in dp0:
-        assert torch.equal(dp0[k], dp[k]), k                      # zero learning rates: nothing moved
+        assert np.array_equal(dp0[k].cpu().numpy(), np.ascontiguousarray(p[k], dtype=np.float32)), k     # zero learning rates: nothing moved
     eng0.close()
     same_lattice = _close(s_fit0.cpu().numpy(), fw["sse"].cpu().numpy(), rtol=2e-6, atol=1e-9)
     assert same_lattice.all(), np.flatnonzero(~same_lattice)
@@ -321,7 +321,12 @@ def test_cfg1_single_block_forward_and_200_iterations():
     # CLI defaults: chaotic (A steps by ~1 per iteration through an 8-bit quantiser) -- judged against the restatement's
     # own fp32-vs-fp64 spread over the six blocks
     assert np.median(d_gpu) <= 1.5 * np.median(d_floor) + 0.05, (d_gpu, d_floor)
-    assert max(d_gpu) <= 2.0 * max(d_floor) + 0.5, (d_gpu, d_floor)
+    # block by block where the restatement itself is reproducible (fp32 and fp64 within 0.5 dB); a block whose own two
+    # precisions end >= 0.5 dB apart (a steering diagonal crossed zero: 7-13 dB here) has no trajectory to compare with
+    for dg, df in zip(d_gpu, d_floor):
+        if df < 0.5:
+            assert dg <= 2.0 * df + 0.5, (d_gpu, d_floor)
+    assert sum(df < 0.5 for df in d_floor) >= 3, d_floor
     # gentle steering step: the contract's 0.05 dB per block (or inside the restatement's own spread where that is larger)
     for dg, df in gentle:
         assert dg <= max(0.05, 2 * df), gentle
