@@ -196,8 +196,10 @@ int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks);
 int smoe_set_center_grid(smoe_handle h, const float* grid);
 
 /* Force the lanes-per-block tiling (16, 32, 64; 0 = automatic).  128 = the 64-lane kernels with ONE block on both
- * wavefronts of a workgroup in smoe_fit (the automatic choice for at most 1 024 blocks of the plain margin-loss graph;
- * other graphs and the evaluation run the plain 64-lane kernel).  Tuning / test hook. */
+ * wavefronts of a workgroup in smoe_fit (other graphs and the evaluation run the plain 64-lane kernel).  216 / 416 / 816 =
+ * the team tiling of smoe_fit with 2 / 4 / 8 wavefronts per workgroup: four blocks per workgroup on the 16-lane layout, the
+ * wavefronts split the pixel rows (csrc/smoe_team.hip.h; the automatic choice for small batches of the plain margin-loss
+ * graph; other graphs and the evaluation choose as with 0).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
 
 /* Partition invariance.  The reference walks ALL blocks of an image in one host loop (smoe.py:1643-1702): a block's

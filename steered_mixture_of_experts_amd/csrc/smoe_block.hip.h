@@ -137,6 +137,17 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #ifndef SMOE_NT_STORES
 #define SMOE_NT_STORES 1
 #endif
+// Diagnostic build (make EXTRA=-DSMOE_PHASE_CLOCKS=1; scripts/phase_clocks.py): lane 0 of every wavefront of workgroup 0 sums the
+// shader-clock cycles it spends in each phase of the fit iteration and leaves them in loss_out[wave * 8 + phase] -- the
+// loss outputs of the first blocks are garbage in such a build.
+#ifndef SMOE_PHASE_CLOCKS
+#define SMOE_PHASE_CLOCKS 0
+#endif
+#if SMOE_PHASE_CLOCKS
+#define SMOE_CLK(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); clk[i] += (float)(_t - clk_last); clk_last = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SMOE_CLK(i) do { } while (0)
+#endif
 #define SMOE_SQ 0.84932180028801904272f
 #define SMOE_INV_SQ 1.17740022503374817543f
 
@@ -1522,6 +1533,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const float beta1 = a.beta1, beta2 = a.beta2, adam_eps = a.eps, clip = a.clip;
     const float reg_pi = a.reg_pi, reg_u = a.reg_u;
 
+#if SMOE_PHASE_CLOCKS
+    float clk[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned long long clk_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; it < a.n_iters; ++it) {
         float acc[Lt::NSLOT];
 #pragma unroll
@@ -1549,6 +1564,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 }
             }
             if (HL > 0) hoist_const<D, C, K, HL, IC>(R, xc);
+            SMOE_CLK(0);
             if constexpr (SSIM) {
                 // the reference's SSIM branch does not use loss_weights (smoe.py:929-1010)
                 // Both sweeps, 16-lane tiling: the full pixel steps run unguarded (uniform control flow), a ragged tail guarded.
@@ -1601,6 +1617,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 else pixel_loop_train<D, C, K, false, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, gl, sl, acc);
             }
             if (HL > 0) complete_const<D, C, K, HL, IC>(R, xc, acc);
+            SMOE_CLK(1);
         }
         if (!owner_post) {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
@@ -1612,8 +1629,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             finish_partials<D, C, K, IC>(R2, kc, acc);
         }
 
+        SMOE_CLK(2);
         float total[T::SPL];
         reduce_slots<D, C, K, G, WAVES, 0>(acc, s_scratch, lane, total);
+        SMOE_CLK(3);
 
         if constexpr (PAIR) {
             // the helper's totals (linear partial sums, like the accumulators) go to the owners through its own scratch
@@ -1631,6 +1650,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 __syncthreads();                           // the owners' Adam step: parameters written
                 b1p *= beta1;
                 b2p *= beta2;
+                SMOE_CLK(4);
                 continue;
             }
 #pragma unroll
@@ -1640,6 +1660,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             }
         }
 
+        SMOE_CLK(4);
         if (owner_post) {
             // raw sums -> gradients on the owner side: publish the raw totals in the (now free) scratch, then every owner
             // evaluates the descriptor of its slot (eval_slot_desc)
@@ -1691,6 +1712,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             wave_lds_sync();
         }
 
+        SMOE_CLK(5);
         // ---- owner phase: TF1 ApplyAdam (smoe.py:1173-1193), prune (1763-1766), stop test (1565-1570)
         const float bias = __builtin_amdgcn_sqrtf(1.0f - b2p) * fast_rcp(1.0f - b1p);   // alpha = lr * sqrt(1-b2^t)/(1-b1^t): one division per iteration
         // gradients w.r.t. the (quantised) graph variables incl. the l1 terms
@@ -1796,11 +1818,20 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             if (j == Lt::S_SSE && !frozen) last_sse = total[s];
         }
         wave_lds_sync();   // every lane has consumed the old flags / params
+        SMOE_CLK(6);
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
                 s_par[j] = newp[s];
+                if constexpr (!QUANT) {
+                    // quantize_pis alone (the CLI default): the owner of a prior publishes its fake-quantised value with the new
+                    // prior itself (one LDS hand-off less per iteration than a separate refresh_quantised_image pass)
+                    if (patch_pis && meta[s] >= 0 && (meta[s] & 15) == 0) {
+                        const float cl = fminf(fmaxf(newp[s], kc.q_nmin[3]), kc.q_nmax[3]);
+                        s_par[Lt::LP_QPI + (meta[s] >> 4)] = floorf((cl - kc.q_nmin[3]) * kc.q_inv[3] + 0.5f) * kc.q_scale[3] + kc.q_nmin[3];
+                    }
+                }
             } else if (j >= Lt::S_CNT && j < Lt::S_CNT + K) {
                 if (!frozen) s_par[Lt::LP_ACT + (j - Lt::S_CNT)] = (total[s] > 0.0f) ? 1.0f : 0.0f;
             } else if (j == Lt::S_LOSS) {
@@ -1808,11 +1839,21 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             }
         }
         wave_lds_sync();
-        if (has_quant) refresh_quantised_image();
+        if constexpr (QUANT) {
+            if (has_quant) refresh_quantised_image();
+        }
         if constexpr (PAIR) __syncthreads();
         b1p *= beta1;
         b2p *= beta2;
+        SMOE_CLK(7);
     }
+#if SMOE_PHASE_CLOCKS
+    if (blockIdx.x == 0 && lane == 0 && a.loss_out != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.loss_out[B / 2 + wave * 8 + i] = clk[i];
+    }
+    return;
+#endif
 
     // ---- write back (pointers are re-read from the kernarg segment: keeping 18 of them
     // live across the iteration loop costs SGPR spills inside it) ------------------------
@@ -2475,7 +2516,8 @@ int fit_occupancy(int N, bool has_lw, int hoist, bool pair) {
     { D, C, K, G, W, "fit_d" SMOE_STR(D) "c" SMOE_STR(C) "k" SMOE_STR(K) "_g" SMOE_STR(G) "w" SMOE_STR(W), &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
       &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W>, \
       &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W>, \
-      &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W> }
+      &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W>, \
+      team_fit_ptr<D, C, K, G, W>(), team_lds_ptr<D, C, K, G, W>(), team_occ_ptr<D, C, K, G, W>() }
 
 // Reduced instantiation for the (dim, channels, kernels) triples outside the BASELINE shapes: the margin loss with and
 // without train_inverse_cov (quantize_pis included: it lives in the default kernels); ssim_opt and quantization_mode
@@ -2483,7 +2525,8 @@ int fit_occupancy(int N, bool has_lw, int hoist, bool pair) {
 #define SMOE_VARIANT_BASIC(D, C, K, G, W) \
     { D, C, K, G, W, "fit_d" SMOE_STR(D) "c" SMOE_STR(C) "k" SMOE_STR(K) "_g" SMOE_STR(G) "w" SMOE_STR(W), &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
       nullptr, nullptr, nullptr, &launch_readmit_quant<D, C, K, G, W>, nullptr, nullptr, \
-      &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W> }
+      &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W>, \
+      team_fit_ptr<D, C, K, G, W>(), team_lds_ptr<D, C, K, G, W>(), team_occ_ptr<D, C, K, G, W>() }
 
 }  // namespace smoe
 #endif

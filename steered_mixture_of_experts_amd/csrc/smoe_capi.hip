@@ -25,6 +25,8 @@ struct smoe_context {
     int pair_occ;        // wavefronts per CU the 64-lane fit kernel reaches (-1: not asked yet)
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     long long total_blocks;   // smoe_set_total_blocks: block count of the whole job the calls are shards of (0: each call's own)
+    int force_team;      // 0: by batch size, 2 / 4 / 8: team tiling with that many wavefronts per workgroup, -1: never
+    std::string variant_name;   // what smoe_fit_variant last returned (the team names are composed)
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
 };
@@ -43,11 +45,38 @@ int fail_hip(hipError_t e, const char* what) {
     return SMOE_ERR_HIP;
 }
 
+// SMOE_HOST_TEST (make hostcheck; tests/host/hostcheck_driver.cpp): the host layer built for a box without a GPU and run
+// under AddressSanitizer + UBSan -- handles are created without a device and without device allocations, and the HIP calls of
+// the entry points (hipSetDevice, copies, kernel launches) are compiled out, so that every entry point runs its argument
+// checks, its kernel-variant selection and its size arithmetic up to the launch.  Never defined in the product build.
+#ifndef SMOE_HOST_TEST
+#define SMOE_HOST_TEST 0
+#endif
+#if SMOE_HOST_TEST
+#define HIP_TRY(expr, what) do { } while (0)
+#else
 #define HIP_TRY(expr, what)                              \
     do {                                                 \
         hipError_t _e = (expr);                          \
         if (_e != hipSuccess) return fail_hip(_e, what); \
     } while (0)
+#endif
+
+// Workspace memory of a handle.  SMOE_HOST_TEST: host heap instead of device memory, so that the sanitizers see every
+// size and every copy of the set-up code.
+#if SMOE_HOST_TEST
+template <typename T> hipError_t dev_malloc(T** p, size_t n) { *p = (T*)std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t dev_upload(void* d, const void* src, size_t n) { std::memcpy(d, src, n); return hipSuccess; }
+hipError_t dev_download(void* d, const void* src, size_t n) { std::memcpy(d, src, n); return hipSuccess; }
+hipError_t dev_zero(void* d, size_t n) { std::memset(d, 0, n); return hipSuccess; }
+void dev_free(void* p) { std::free(p); }
+#else
+template <typename T> hipError_t dev_malloc(T** p, size_t n) { return hipMalloc(p, n); }
+hipError_t dev_upload(void* d, const void* src, size_t n) { return dev_upload(d, src, n); }
+hipError_t dev_download(void* d, const void* src, size_t n) { return dev_download(d, src, n); }
+hipError_t dev_zero(void* d, size_t n) { return hipMemset(d, 0, n); }
+void dev_free(void* p) { (void)hipFree(p); }
+#endif
 
 // numpy.linspace(0, 1, n) as gen_domain uses it (smoe.py:2412): arange(n) * step, the
 // last sample forced to the end point; fed to the graph as float32 (smoe.py:545).
@@ -184,6 +213,9 @@ int wanted_lanes(const smoe_context* h, int num_blocks) {
 // provided the kernel's registers let two wavefronts share a SIMD.  Measured (scripts/pair_check.py): ONE 512x512 image
 // 86 -> 93 Gpx-it/s, 1 020 blocks of 16x16x4 RGB 92 -> 123; 1 536 blocks 124 -> 108 (no longer pays).
 constexpr int PAIR_MAX_BLOCKS = 1024;
+#ifndef SMOE_TEAM_MAX_BLOCKS
+#define SMOE_TEAM_MAX_BLOCKS 0          // automatic team tiling up to this many blocks (0: only when forced, smoe_set_tiling)
+#endif
 bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
     if (v->G != 64 || v->W != 2 || h->N < 128) return false;
     if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov) return false;
@@ -191,6 +223,36 @@ bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
     if (choice_blocks(h, num_blocks) > PAIR_MAX_BLOCKS) return false;
     if (h->pair_occ < 0) h->pair_occ = v->fit_waves_per_cu(h->N, false, hoist_level(h, v), true);   // of the PAIR kernel itself
     return h->pair_occ >= 8;                                   // two wavefronts per SIMD can be resident together
+}
+
+// Team tiling (smoe_team.hip.h): four blocks per workgroup on the 16-lane layout, the workgroup's wavefronts split the pixel
+// rows.  Returns the wavefronts per workgroup (2, 4, 8) or 0 = run the regular kernels.  The default margin-loss graph only
+// (with quantize_pis, the l1 terms, loss weights), block shapes whose last axis divides 16.
+const smoe::Variant* find_g16(const smoe_context* h) {
+    int n = 0;
+    const smoe::Variant* v = smoe::variants(&n);
+    for (int i = 0; i < n; ++i)
+        if (v[i].D == h->cfg.dim && v[i].C == h->cfg.channels && v[i].K == h->cfg.kernels && v[i].G == 16 && v[i].fit_team) return &v[i];
+    return nullptr;
+}
+
+int team_waves(const smoe_context* h, int num_blocks, bool has_lw, const smoe::Variant** v16_out) {
+    if (h->force_team < 0 || (h->force_g && h->force_team == 0)) return 0;
+    if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov || h->kc.radial) return 0;
+    const smoe::Variant* v16 = find_g16(h);
+    if (!v16 || hoist_level(h, v16) < 1) return 0;
+    int nw = h->force_team;
+    if (nw == 0) {
+        // measured crossings (profiles/r03/bench_shapes.txt): below ~16 000 blocks the 16-lane kernels leave SIMDs with fewer
+        // than four wavefronts; the team keeps the wavefront count up with the cheap per-block overhead of that tiling
+        const int cb = choice_blocks(h, num_blocks);
+        if (h->N > 512) return 0;
+        if (cb > SMOE_TEAM_MAX_BLOCKS) return 0;
+        nw = (cb <= 3072) ? 8 : ((cb <= 6144) ? 4 : 2);
+    }
+    if (v16->team_lds_bytes(h->N, has_lw, nw) > 160u * 1024u) return 0;
+    if (v16_out) *v16_out = v16;
+    return nw;
 }
 
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
@@ -286,11 +348,13 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
                  cfg->dim, cfg->channels, cfg->kernels);
         return fail(SMOE_ERR_UNSUPPORTED, buf);
     }
+#if !SMOE_HOST_TEST
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(SMOE_ERR_NO_DEVICE, "smoe_create: no HIP device visible (this library has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(SMOE_ERR_INVALID, "smoe_create: device ordinal out of range");
     HIP_TRY(hipSetDevice(cfg->device), "hipSetDevice");
+#endif
 
     smoe_context* h = new (std::nothrow) smoe_context();
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_create: out of host memory");
@@ -298,6 +362,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->N = (int)N;
     h->force_g = 0;
     h->force_pair = 0;
+    h->force_team = 0;
     h->total_blocks = 0;
     h->pair_occ = -1;
     h->big_g = -1;
@@ -328,25 +393,25 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         probes[l * 3 + 1] = (float)mx;
         probes[l * 3 + 2] = (float)((mn + mx) / 2.0);
     }
-    hipError_t e = hipMalloc(&h->d_coords, sizeof(float) * D * N);
-    if (e == hipSuccess) e = hipMalloc(&h->d_probes, sizeof(float) * D * 3);
-    if (e == hipSuccess) e = hipMemcpy(h->d_coords, h->h_coords.data(), sizeof(float) * D * N, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * D * 3, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&h->d_partials, sizeof(double) * smoe::reduce_partials_count());
+    hipError_t e = dev_malloc(&h->d_coords, sizeof(float) * D * N);
+    if (e == hipSuccess) e = dev_malloc(&h->d_probes, sizeof(float) * D * 3);
+    if (e == hipSuccess) e = dev_upload(h->d_coords, h->h_coords.data(), sizeof(float) * D * N);
+    if (e == hipSuccess) e = dev_upload(h->d_probes, probes.data(), sizeof(float) * D * 3);
+    if (e == hipSuccess) e = dev_malloc(&h->d_partials, sizeof(double) * smoe::reduce_partials_count());
     if (e == hipSuccess && cfg->ssim_opt) {
         const int bh = cfg->block_shape[0], bw = cfg->block_shape[1], bt = (cfg->dim == 3) ? cfg->block_shape[2] : 0;
         std::vector<float> tabs((size_t)11 * (bh + bw + bt));
         ssim_axis_table(bh, tabs.data());
         ssim_axis_table(bw, tabs.data() + (size_t)11 * bh);
         if (bt) ssim_axis_table(bt, tabs.data() + (size_t)11 * (bh + bw));
-        e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
-        if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
+        e = dev_malloc(&h->d_ssim_T, sizeof(float) * tabs.size());
+        if (e == hipSuccess) e = dev_upload(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size());
     }
     if (e != hipSuccess) {
-        if (h->d_coords) (void)hipFree(h->d_coords);
-        if (h->d_probes) (void)hipFree(h->d_probes);
-        if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
-        if (h->d_partials) (void)hipFree(h->d_partials);
+        if (h->d_coords) dev_free(h->d_coords);
+        if (h->d_probes) dev_free(h->d_probes);
+        if (h->d_ssim_T) dev_free(h->d_ssim_T);
+        if (h->d_partials) dev_free(h->d_partials);
         delete h;
         return fail_hip(e, "smoe_create: workspace");
     }
@@ -403,11 +468,13 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
 
 int smoe_destroy(smoe_handle h) {
     if (!h) return SMOE_OK;
+#if !SMOE_HOST_TEST
     (void)hipSetDevice(h->cfg.device);
-    if (h->d_coords) (void)hipFree(h->d_coords);
-    if (h->d_probes) (void)hipFree(h->d_probes);
-    if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
-    if (h->d_partials) (void)hipFree(h->d_partials);
+#endif
+    if (h->d_coords) dev_free(h->d_coords);
+    if (h->d_probes) dev_free(h->d_probes);
+    if (h->d_ssim_T) dev_free(h->d_ssim_T);
+    if (h->d_partials) dev_free(h->d_partials);
     delete h;
     return SMOE_OK;
 }
@@ -415,7 +482,7 @@ int smoe_destroy(smoe_handle h) {
 int smoe_get_coords(smoe_handle h, float* host_out) {
     if (!h || !host_out) return fail(SMOE_ERR_INVALID, "smoe_get_coords: null argument");
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
-    HIP_TRY(hipMemcpy(host_out, h->d_coords, sizeof(float) * h->cfg.dim * h->N, hipMemcpyDeviceToHost), "smoe_get_coords");
+    HIP_TRY(dev_download(host_out, h->d_coords, sizeof(float) * h->cfg.dim * h->N), "smoe_get_coords");
     return SMOE_OK;
 }
 
@@ -427,12 +494,16 @@ int smoe_set_center_grid(smoe_handle h, const float* grid) {
 
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_tiling: null handle");
-    if (lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64 && lanes_per_block != 128)
-        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32, 64 or 128");
+    const bool team = lanes_per_block == 216 || lanes_per_block == 416 || lanes_per_block == 816;
+    if (!team && lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64 && lanes_per_block != 128)
+        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32, 64, 128, 216, 416 or 816");
     // 128 = the 64-lane kernels with one block on both wavefronts of a workgroup (margin loss, quantization_mode 0 / 1,
     // train_inverse_cov off; other graphs run the plain 64-lane kernel)
-    h->force_g = (lanes_per_block == 128) ? 64 : lanes_per_block;
-    h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0) ? 0 : -1);
+    // 216 / 416 / 816 = team tiling with 2 / 4 / 8 wavefronts per workgroup in smoe_fit (the graphs it covers; others and
+    // the evaluation choose as with 0)
+    h->force_g = (lanes_per_block == 128) ? 64 : (team ? 0 : lanes_per_block);
+    h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0 || team) ? 0 : -1);
+    h->force_team = team ? lanes_per_block / 100 : ((lanes_per_block == 0) ? 0 : -1);
     return SMOE_OK;
 }
 
@@ -445,6 +516,15 @@ int smoe_set_total_blocks(smoe_handle h, int64_t total_blocks) {
 
 const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks) {
     if (!h) return "";
+    const smoe::Variant* v16 = nullptr;
+    const int nw = team_waves(h, num_blocks, false, &v16);
+    if (nw > 0) {
+        h->variant_name = std::string(v16->name);
+        const size_t g = h->variant_name.find("_g16");
+        if (g != std::string::npos) h->variant_name.resize(g);
+        h->variant_name += "_team16w" + std::to_string(nw);
+        return h->variant_name.c_str();
+    }
     const smoe::Variant* v = find_variant(h, num_blocks, false);
     return v ? v->name : "";
 }
@@ -454,6 +534,9 @@ int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks) {
     const smoe::Variant* v = find_variant(h, num_blocks, false);
     if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_fit_occupancy: no variant");
     if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SMOE_ERR_HIP, "hipSetDevice");
+    const smoe::Variant* v16 = nullptr;
+    const int nw = team_waves(h, num_blocks, false, &v16);
+    if (nw > 0) return v16->team_waves_per_cu(h->N, false, nw);
     return v->fit_waves_per_cu(h->N, false, hoist_level(h, v), false);
 }
 
@@ -512,7 +595,10 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1]; a.bt = c.block_shape[2];
     a.pair = wants_pair(h, v, num_blocks) ? 1 : 0;
     a.mus_grid = h->mus_grid;
-    if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
+    const smoe::Variant* v16 = nullptr;
+    const int team = team_waves(h, num_blocks, loss_w != nullptr, &v16);
+    if (team > 0) HIP_TRY(v16->fit_team(a, hoist_level(h, v16), team, (hipStream_t)stream), "smoe_fit (team) launch");
+    else if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fit_ic(a, hoist, (hipStream_t)stream), "smoe_fit (inverse covariance) launch");
     else HIP_TRY(v->fit(a, hoist, (hipStream_t)stream), "smoe_fit launch");
@@ -668,11 +754,13 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     const int KW = (cfg->kernels + 31) / 32;
     if (smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, KW) > 160u * 1024u)
         return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: kernel list does not fit in LDS");
+#if !SMOE_HOST_TEST
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(SMOE_ERR_NO_DEVICE, "smoe_shared_create: no HIP device visible (this library has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(SMOE_ERR_INVALID, "smoe_shared_create: device ordinal out of range");
     HIP_TRY(hipSetDevice(cfg->device), "hipSetDevice");
+#endif
     smoe_shared_context* h = new (std::nothrow) smoe_shared_context();
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_create: out of host memory");
     h->cfg = *cfg;
@@ -726,29 +814,29 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
             return fail(SMOE_ERR_UNSUPPORTED, "smoe_shared_create: ssim_opt planes of this batch size do not fit in LDS");
         }
     }
-    hipError_t e = hipMalloc(&h->d_axes, sizeof(float) * axes.size());
-    if (e == hipSuccess) e = hipMalloc(&h->d_probes, sizeof(float) * probes.size());
-    if (e == hipSuccess) e = hipMalloc(&h->d_racc, sizeof(double) * nacc);
-    if (e == hipSuccess) e = hipMemcpy(h->d_axes, axes.data(), sizeof(float) * axes.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(h->d_probes, probes.data(), sizeof(float) * probes.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(h->d_racc, 0, sizeof(double) * nacc);
-    if (e == hipSuccess) e = hipMalloc(&h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
-    if (e == hipSuccess) e = hipMemset(h->d_qrng, 0, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
+    hipError_t e = dev_malloc(&h->d_axes, sizeof(float) * axes.size());
+    if (e == hipSuccess) e = dev_malloc(&h->d_probes, sizeof(float) * probes.size());
+    if (e == hipSuccess) e = dev_malloc(&h->d_racc, sizeof(double) * nacc);
+    if (e == hipSuccess) e = dev_upload(h->d_axes, axes.data(), sizeof(float) * axes.size());
+    if (e == hipSuccess) e = dev_upload(h->d_probes, probes.data(), sizeof(float) * probes.size());
+    if (e == hipSuccess) e = dev_zero(h->d_racc, sizeof(double) * nacc);
+    if (e == hipSuccess) e = dev_malloc(&h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
+    if (e == hipSuccess) e = dev_zero(h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess && cfg->ssim_opt) {
         const int bh = cfg->batch_shape[0], bw = cfg->batch_shape[1], bt = (cfg->dim == 3) ? cfg->batch_shape[2] : 0;
         std::vector<float> tabs((size_t)11 * (bh + bw + bt));
         ssim_axis_table(bh, tabs.data());
         ssim_axis_table(bw, tabs.data() + (size_t)11 * bh);
         if (bt) ssim_axis_table(bt, tabs.data() + (size_t)11 * (bh + bw));
-        e = hipMalloc(&h->d_ssim_T, sizeof(float) * tabs.size());
-        if (e == hipSuccess) e = hipMemcpy(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size(), hipMemcpyHostToDevice);
+        e = dev_malloc(&h->d_ssim_T, sizeof(float) * tabs.size());
+        if (e == hipSuccess) e = dev_upload(h->d_ssim_T, tabs.data(), sizeof(float) * tabs.size());
     }
     if (e != hipSuccess) {
-        if (h->d_axes) (void)hipFree(h->d_axes);
-        if (h->d_probes) (void)hipFree(h->d_probes);
-        if (h->d_racc) (void)hipFree(h->d_racc);
-        if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
-        if (h->d_qrng) (void)hipFree(h->d_qrng);
+        if (h->d_axes) dev_free(h->d_axes);
+        if (h->d_probes) dev_free(h->d_probes);
+        if (h->d_racc) dev_free(h->d_racc);
+        if (h->d_ssim_T) dev_free(h->d_ssim_T);
+        if (h->d_qrng) dev_free(h->d_qrng);
         delete h;
         return fail_hip(e, "smoe_shared_create: workspace");
     }
@@ -787,12 +875,14 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
 
 int smoe_shared_destroy(smoe_shared_handle h) {
     if (!h) return SMOE_OK;
+#if !SMOE_HOST_TEST
     (void)hipSetDevice(h->cfg.device);
-    if (h->d_axes) (void)hipFree(h->d_axes);
-    if (h->d_probes) (void)hipFree(h->d_probes);
-    if (h->d_racc) (void)hipFree(h->d_racc);
-    if (h->d_ssim_T) (void)hipFree(h->d_ssim_T);
-    if (h->d_qrng) (void)hipFree(h->d_qrng);
+#endif
+    if (h->d_axes) dev_free(h->d_axes);
+    if (h->d_probes) dev_free(h->d_probes);
+    if (h->d_racc) dev_free(h->d_racc);
+    if (h->d_ssim_T) dev_free(h->d_ssim_T);
+    if (h->d_qrng) dev_free(h->d_qrng);
     delete h;
     return SMOE_OK;
 }

@@ -123,6 +123,10 @@ struct Variant {
     hipError_t (*fwd_quant)(const FwdArgs&, hipStream_t);
     hipError_t (*fit_ic)(const FitArgs&, int hoist_level, hipStream_t);                  // train_inverse_cov
     hipError_t (*fwd_ic)(const FwdArgs&, hipStream_t);
+    // team tiling (smoe_team.hip.h; entries of the 16-lane variants only): four blocks per workgroup of nw wavefronts
+    hipError_t (*fit_team)(const FitArgs&, int hoist_level, int nw, hipStream_t);
+    size_t (*team_lds_bytes)(int N, bool has_lw, int nw);
+    int (*team_waves_per_cu)(int N, bool has_lw, int nw);
 };
 
 // ---- shared-kernel image mode (smoe_shared.hip) ----------------------------------------------

@@ -96,6 +96,80 @@ def _fake_quant_fixed(x: torch.Tensor, lb: float, ub: float, bits: int) -> torch
     return torch.floor((cl - nmin.to(x.device)) * (1.0 / scale).to(x.device) + 0.5) * scale.to(x.device) + nmin.to(x.device)
 
 
+def _train_loop(m, num_iter, val_iter, ukl_iter, pis_l1, u_l1, callbacks, chunk_limit=None):
+    """The iteration / validation / stop logic of ``Smoe.train`` (smoe.py:1485-1603), shared by both facades.  ``m`` supplies
+    ``run_batched`` and four hooks: ``_quantize`` (quantize_params [+ rescaler], smoe.py:1498-1505,1539-1545),
+    ``_fit_iterations(n)`` (n training passes), ``_readmit_kernels`` (update_kernel_list, smoe.py:1531-1536) and
+    ``_keep_best(loss)`` (best snapshot, smoe.py:1574-1576).  The iterations up to the next validation / kernel-list boundary
+    run as ONE engine call (``chunk_limit`` = 1 for a fresh pixel draw per pass)."""
+    if m.quantization_mode >= 1:                                      # smoe.py:1498-1499
+        m._quantize()
+    if m.quantization_mode == 1:                                      # smoe.py:1500-1505
+        m.best_qloss, m.best_qmse, _, _ = m.run_batched(
+            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True, with_quantized_params=True)
+        m.qlosses.append((0, m.best_qloss))
+        m.qmses.append((0, m.best_qmse))
+    # iteration-0 evaluation (smoe.py:1507-1519)
+    m.best_loss, m.best_mse, num_pi, num_sv = m.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+    m._after_first_evaluation()
+    m.losses.append((m.iter, m.best_loss))
+    m.mses.append((m.iter, m.best_mse))
+    m.num_pis.append((m.iter, num_pi))
+    m.num_svs.append((m.iter, num_sv))
+    for callback in callbacks:
+        callback(m)
+
+    loss_val, mse_val = m.best_loss, m.best_mse
+    i = 0
+    try:
+        while i < num_iter:
+            # run up to the next validation / kernel-list boundary in ONE launch
+            nxt = min(num_iter, (i // val_iter + 1) * val_iter, (i // ukl_iter + 1) * ukl_iter)
+            if chunk_limit:
+                nxt = min(nxt, i + chunk_limit)
+            n = nxt - i
+            m._fit_iterations(n)
+            i = nxt
+            m.iter += n
+            m.valid = False
+            validate = i % val_iter == 0
+            if i % ukl_iter == 0:                                         # smoe.py:1531-1536
+                m._readmit_kernels()
+                if not validate:
+                    loss_val, mse_val, num_pi, num_sv = m.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
+            if validate:                                                  # smoe.py:1538-1594
+                if m.quantization_mode >= 1:                              # smoe.py:1539-1540
+                    m._quantize()
+                if m.quantization_mode == 1:                              # smoe.py:1541-1545,1585-1587
+                    qloss_val, qmse_val, _, _ = m.run_batched(
+                        pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True, with_quantized_params=True)
+                    m.qlosses.append((i, qloss_val))
+                    m.qmses.append((i, qmse_val))
+                loss_val, mse_val, num_pi, num_sv = m.run_batched(
+                    pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+                # global divergence rule at validation cadence (per block it is applied on the device every iteration,
+                # smoe.py:1565-1570)
+                if np.isnan(loss_val) or (len(m.losses) > 0 and loss_val + 1 > (m.losses[0][1] + 100) * 10):
+                    print("stop")
+                    break
+                m._keep_best(loss_val)
+                m.losses.append((m.iter, loss_val))
+                if not m.best_mse or mse_val < m.best_mse:
+                    m.best_mse = mse_val
+                m.mses.append((m.iter, mse_val))
+                m.num_pis.append((m.iter, num_pi))
+                m.num_svs.append((m.iter, num_sv))
+                for callback in callbacks:
+                    callback(m)
+    except KeyboardInterrupt:
+        pass
+    m.losses_history.append(m.losses)
+    m.mses_history.append(m.mses)
+    if m.rank == 0:
+        print("end loss/mse: ", loss_val, "/", mse_val, "@iter: ", i)
+        print("best loss/mse: ", m.best_loss, "/", m.best_mse)
+
+
 class Smoe:
     def __init__(self, image, kernels_per_dim=None, train_pis=True, init_params=None, start_batches=1,
                  batch_size=None, train_gammas=True, train_musx=True, use_diff_center=False, radial_as=False,
@@ -482,91 +556,39 @@ class Smoe:
         assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
         if with_inc or train_inc or not train_orig:
             raise NotImplementedError("kernel-adding options are outside the hot path")
-        sampling = (sampling_percentage < 100) and not self.ssim_opt
+        self._train_sampling = sampling_percentage if (sampling_percentage < 100 and not self.ssim_opt) else None
         self._make_engine(pis_l1, u_l1)
-        eng = self._engine
+        _train_loop(self, num_iter, val_iter, ukl_iter, pis_l1, u_l1, callbacks,
+                    chunk_limit=1 if self._train_sampling is not None else None)   # a fresh pixel draw per pass (smoe.py:1664-1667)
 
-        if self.quantization_mode >= 1:                                   # smoe.py:1498-1499
-            from .quantizer import quantize_params, rescaler
-            self.qparams = quantize_params(self, self.get_params())
-        if self.quantization_mode == 1:                                   # smoe.py:1500-1505
+    # hooks of _train_loop
+    def _quantize(self):
+        from .quantizer import quantize_params, rescaler
+        self.qparams = quantize_params(self, self.get_params())
+        if self.quantization_mode == 1:
             self.rparams = rescaler(self, self.qparams)
-            self.best_qloss, self.best_qmse, _, _ = self.run_batched(
-                pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True, with_quantized_params=True)
-            self.qlosses.append((0, self.best_qloss))
-            self.qmses.append((0, self.best_qmse))
-        # iteration-0 evaluation (smoe.py:1507-1519)
-        self.best_loss, self.best_mse, num_pi, num_sv = self.run_batched(
-            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
+
+    def _after_first_evaluation(self):
         if self._loss0 is None:
             self._loss0 = self._last_block_loss.clone()
         if self._best_loss_blocks is None:
             self._best_loss_blocks = self._last_block_loss.clone()
             for k in PARAM_NAMES:
                 self._best[k].copy_(self._params[k])
-        self.losses.append((self.iter, self.best_loss))
-        self.mses.append((self.iter, self.best_mse))
-        self.num_pis.append((self.iter, num_pi))
-        self.num_svs.append((self.iter, num_sv))
-        for callback in callbacks:
-            callback(self)
 
-        loss_val, mse_val = self.best_loss, self.best_mse
-        i = 0
-        try:
-            while i < num_iter:
-                # run up to the next validation / kernel-list boundary in ONE launch
-                nxt = min(num_iter, (i // val_iter + 1) * val_iter, (i // ukl_iter + 1) * ukl_iter)
-                if sampling:
-                    nxt = i + 1                                               # a fresh pixel draw per pass (smoe.py:1664-1667)
-                n = nxt - i
-                eng.fit(self._target, self._params, self._state, self._active, n,
-                        loss_w=self._sample_pixels(sampling_percentage) if sampling else self._loss_w,
-                        diverged=self._diverged, loss0=self._loss0)
-                i = nxt
-                self.iter += n
-                self.valid = False
-                validate = i % val_iter == 0
-                if i % ukl_iter == 0:                                         # smoe.py:1531-1536
-                    eng.update_kernel_list(self._params, self._active)
-                    if not validate:
-                        loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
-                if validate:                                                  # smoe.py:1538-1594
-                    if self.quantization_mode >= 1:                           # smoe.py:1539-1540
-                        from .quantizer import quantize_params, rescaler
-                        self.qparams = quantize_params(self, self.get_params())
-                    if self.quantization_mode == 1:                           # smoe.py:1541-1545
-                        self.rparams = rescaler(self, self.qparams)
-                        qloss_val, qmse_val, _, _ = self.run_batched(
-                            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True,
-                            with_quantized_params=True)
-                        self.qlosses.append((i, qloss_val))                   # smoe.py:1585-1587
-                        self.qmses.append((i, qmse_val))
-                    loss_val, mse_val, num_pi, num_sv = self.run_batched(
-                        pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
-                    # global divergence rule at validation cadence (per block it is applied on the
-                    # device every iteration, smoe.py:1565-1570)
-                    if np.isnan(loss_val) or (len(self.losses) > 0 and loss_val + 1 > (self.losses[0][1] + 100) * 10):
-                        print("stop")
-                        break
-                    eng.checkpoint_best(self._last_block_loss, self._best_loss_blocks, self._params, self._best)
-                    if not self.best_loss or loss_val < self.best_loss:
-                        self.best_loss = loss_val
-                    self.losses.append((self.iter, loss_val))
-                    if not self.best_mse or mse_val < self.best_mse:
-                        self.best_mse = mse_val
-                    self.mses.append((self.iter, mse_val))
-                    self.num_pis.append((self.iter, num_pi))
-                    self.num_svs.append((self.iter, num_sv))
-                    for callback in callbacks:
-                        callback(self)
-        except KeyboardInterrupt:
-            pass
-        self.losses_history.append(self.losses)
-        self.mses_history.append(self.mses)
-        if self.rank == 0:
-            print("end loss/mse: ", loss_val, "/", mse_val, "@iter: ", i)
-            print("best loss/mse: ", self.best_loss, "/", self.best_mse)
+    def _fit_iterations(self, n):
+        sp = getattr(self, "_train_sampling", None)
+        self._engine.fit(self._target, self._params, self._state, self._active, n,
+                         loss_w=self._sample_pixels(sp) if sp is not None else self._loss_w,
+                         diverged=self._diverged, loss0=self._loss0)
+
+    def _readmit_kernels(self):
+        self._engine.update_kernel_list(self._params, self._active)
+
+    def _keep_best(self, loss_val):
+        self._engine.checkpoint_best(self._last_block_loss, self._best_loss_blocks, self._params, self._best)
+        if not self.best_loss or loss_val < self.best_loss:
+            self.best_loss = loss_val
 
     # -- getters (smoe.py:1795-1888) ------------------------------------------------------------
     def _gather_params(self, p: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
@@ -919,73 +941,31 @@ class SharedSmoe:
         if optimizer1:
             self.set_optimizer(optimizer1, optimizer2, optimizer3, grad_clip_value_abs=grad_clip_value_abs)
         assert self.optimizer1 is not None, "no optimizer found, you have to specify one!"
-        if self.quantization_mode >= 1:                                   # smoe.py:1498-1505
-            self._quantize()
-        if self.quantization_mode == 1:
-            self.best_qloss, self.best_qmse, _, _ = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False,
-                                                                     update_reconstruction=True, with_quantized_params=True)
-            self.qlosses.append((0, self.best_qloss))
-            self.qmses.append((0, self.best_qmse))
-        self.best_loss, self.best_mse, num_pi, num_sv = self.run_batched(
-            pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
-        self.losses.append((self.iter, self.best_loss))
-        self.mses.append((self.iter, self.best_mse))
-        self.num_pis.append((self.iter, num_pi))
-        self.num_svs.append((self.iter, num_sv))
-        for cb in callbacks:
-            cb(self)
-        loss_val, mse_val = self.best_loss, self.best_mse
+        self._make_engine(pis_l1, u_l1)
+        _train_loop(self, num_iter, val_iter, ukl_iter, pis_l1, u_l1, callbacks)
+
+    # hooks of _train_loop
+    def _after_first_evaluation(self):
+        pass
+
+    def _fit_iterations(self, n):
         eng = self._engine
-        single = self.world_size == 1
-        i = 0
-        while i < num_iter:
-            nxt = min(num_iter, (i // val_iter + 1) * val_iter, (i // ukl_iter + 1) * ukl_iter)
-            n = nxt - i
-            if single:                                                       # n x (accumulate; apply) in one call
-                eng.fit(self._target, self._params, self._state, self._lists, n)
-            else:
-                for _ in range(n):
-                    eng.accumulate(self._target, self._params, self._lists, first_batch=self.lo)
-                    sdist.allreduce_sum_(eng.grad_buffer())
-                    eng.apply(self._params, self._state)
-            i = nxt
-            self.iter += n
-            self.valid = False
-            validate = i % val_iter == 0
-            if i % ukl_iter == 0:                                            # smoe.py:1531-1536
-                eng.update_kernel_list(self._params, self._lists, first_batch=self.lo)
-                if not validate:
-                    loss_val, mse_val, num_pi, num_sv = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False)
-            if validate:
-                if self.quantization_mode >= 1:                               # smoe.py:1539-1545,1585-1587
-                    self._quantize()
-                if self.quantization_mode == 1:
-                    qloss_val, qmse_val, _, _ = self.run_batched(pis_l1=pis_l1, u_l1=u_l1, train=False,
-                                                                 update_reconstruction=True, with_quantized_params=True)
-                    self.qlosses.append((i, qloss_val))
-                    self.qmses.append((i, qmse_val))
-                loss_val, mse_val, num_pi, num_sv = self.run_batched(
-                    pis_l1=pis_l1, u_l1=u_l1, train=False, update_reconstruction=True)
-                if np.isnan(loss_val) or loss_val + 1 > (self.losses[0][1] + 100) * 10:   # smoe.py:1565-1570
-                    print("stop")
-                    break
-                if not self.best_loss or loss_val < self.best_loss:           # smoe.py:1574-1576
-                    self.best_loss = loss_val
-                    for k in PARAM_NAMES:
-                        self._best[k].copy_(self._params[k])
-                self.losses.append((self.iter, loss_val))
-                if not self.best_mse or mse_val < self.best_mse:
-                    self.best_mse = mse_val
-                self.mses.append((self.iter, mse_val))
-                self.num_pis.append((self.iter, num_pi))
-                self.num_svs.append((self.iter, num_sv))
-                for cb in callbacks:
-                    cb(self)
-        self.losses_history.append(self.losses)
-        self.mses_history.append(self.mses)
-        if self.rank == 0:
-            print("end loss/mse: ", loss_val, "/", mse_val, "@iter: ", i)
-            print("best loss/mse: ", self.best_loss, "/", self.best_mse)
+        if self.world_size == 1:                                             # n x (accumulate; apply) in one call
+            eng.fit(self._target, self._params, self._state, self._lists, n)
+        else:
+            for _ in range(n):
+                eng.accumulate(self._target, self._params, self._lists, first_batch=self.lo)
+                sdist.allreduce_sum_(eng.grad_buffer())                      # the gradient exchange of the pass
+                eng.apply(self._params, self._state)
+
+    def _readmit_kernels(self):
+        self._engine.update_kernel_list(self._params, self._lists, first_batch=self.lo)
+
+    def _keep_best(self, loss_val):
+        if not self.best_loss or loss_val < self.best_loss:                  # smoe.py:1574-1576
+            self.best_loss = loss_val
+            for k in PARAM_NAMES:
+                self._best[k].copy_(self._params[k])
 
     def _host_params(self, p):
         out = {k: v.cpu().numpy().copy() for k, v in p.items()}

@@ -48,7 +48,11 @@ EXTRA_SHAPES = [
 ALL_SHAPES = [(s, 16) for s in SHAPES] + [(s, 64) for s in SHAPES] + [(s, 32) for s in SHAPES[:5]] \
     + [(s, 16) for s in EXTRA_SHAPES] + [(s, 64) for s in EXTRA_SHAPES]
 # 128 = one block on both wavefronts of a workgroup (smoe_fit only: the evaluation has no such mode)
-FIT_SHAPES = ALL_SHAPES + [(s, 128) for s in SHAPES] + [(s, 128) for s in EXTRA_SHAPES[::3]]
+# 216 / 416 / 816 = team tiling of smoe_fit (csrc/smoe_team.hip.h): four blocks per workgroup of 2 / 4 / 8 wavefronts on the
+# 16-lane layout; block shapes whose last axis divides 16
+TEAM_OK = [s for s in SHAPES + EXTRA_SHAPES if 16 % s[0][-1] == 0]
+FIT_SHAPES = ALL_SHAPES + [(s, 128) for s in SHAPES] + [(s, 128) for s in EXTRA_SHAPES[::3]] \
+    + [(s, 816) for s in TEAM_OK] + [(s, 416) for s in TEAM_OK[:6]] + [(s, 216) for s in TEAM_OK[:6]]
 
 
 def _ids(cases):
@@ -181,6 +185,7 @@ def test_one_step_parity(case, tiling):
     active = np.ones((B, K), dtype=bool)
     eng = _engine(shape, C, K, use_yuv=yuv)
     eng.set_tiling(tiling)
+    assert ("team16w%d" % (tiling // 100) in eng.fit_variant(B)) == (tiling > 128)
     dp = _to_dev(p)
     act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
     T = _planar(tgt)
@@ -368,6 +373,46 @@ def test_short_trajectory_vs_sensitivity_floor():
     eng.close()
 
 
+@pytest.mark.parametrize("tiling,B", [(816, 1024), (416, 37), (216, 150)])
+def test_team_tiling_follows_the_restatement_over_a_trajectory(tiling, B):
+    """The team kernel (four blocks per workgroup, the wavefronts split the pixel rows; double-buffered parameters, derived
+    constants published by the slot owners) over 40 iterations incl. the kernel-list pruning and a batch that does not fill
+    the last workgroup: parameters, kernel lists and losses follow the fp32 restatement inside its own fp32-vs-fp64 floor;
+    two runs are bit-identical; with quantize_pis (the CLI default)."""
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 1234, perturb=False, lr_steer=1e-2, quantize_pis=True)
+    n = 40
+    p32, _, i32 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float32)
+    p64, _, i64 = o.fit(p, tgt, coords, cfg, n, val_iter=10 ** 9, dtype=np.float64)
+    T = _planar(tgt)
+    runs = []
+    for _ in range(2):
+        eng = _engine(shape, C, K, lr_steer=1e-2, quantize_pis=True)
+        eng.set_tiling(tiling)
+        assert "team16w%d" % (tiling // 100) in eng.fit_variant(B)
+        dp = _to_dev(p)
+        state = eng.new_adam_state(dp)
+        act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
+        f0 = eng.forward(T, dp, act, want_recon=False)
+        loss = torch.zeros(B, device="cuda")
+        eng.fit(T, dp, state, act, n // 2, loss0=f0["loss"])
+        eng.fit(T, dp, state, act, n - n // 2, loss0=f0["loss"], loss_out=loss)          # state carried across launches
+        torch.cuda.synchronize()
+        runs.append((_to_host(dp), _to_host(state.m), act.cpu().numpy().copy(), loss.cpu().numpy().copy()))
+        eng.close()
+    for name in o.PARAM_NAMES:
+        assert np.array_equal(runs[0][0][name], runs[1][0][name]) and np.array_equal(runs[0][1][name], runs[1][1][name]), name
+    assert np.array_equal(runs[0][2], runs[1][2])
+    got = runs[0][0]
+    for name in o.PARAM_NAMES:
+        dev = np.abs(got[name] - p32[name])
+        floor = np.abs(p32[name] - p64[name])
+        assert np.median(dev) <= 3 * np.median(floor) + 1e-5, (name, np.median(dev), np.median(floor))
+        assert np.isfinite(got[name]).all()
+    same_lists = (_bits_to_mask(runs[0][2].view(np.uint32), K) == i32["active"]).all(axis=1)
+    assert same_lists.mean() > 0.97
+
+
 def test_gentle_lr_trajectory_tight():
     """With a small steering learning rate the dynamics are well conditioned and the GPU
     follows the restatement closely over 50 steps."""
@@ -393,11 +438,13 @@ def test_gentle_lr_trajectory_tight():
     eng.close()
 
 
-def test_frozen_blocks_and_divergence_flag():
+@pytest.mark.parametrize("tiling", [0, 416, 816])
+def test_frozen_blocks_and_divergence_flag(tiling):
     shape, C, kpd = (16, 16), 1, [2, 2]
     B = 8
     cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 4242, perturb=False)
     eng = _engine(shape, C, K)
+    eng.set_tiling(tiling)
     dp = _to_dev(p)
     before = _to_host(dp)
     state = eng.new_adam_state(dp)
@@ -472,7 +519,7 @@ def test_error_paths():
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [16, 64, 128])
+@pytest.mark.parametrize("tiling", [16, 64, 128, 216, 816])
 def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     """The fit kernel's per-pixel loss-weight path (padding / loss masks, smoe.py:550,932), the l1
     regularisers (smoe.py:1027,1044) and gradient clipping (smoe.py:1152-1153) against the oracle."""
@@ -518,7 +565,7 @@ def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [16, 64, 128])
+@pytest.mark.parametrize("tiling", [16, 64, 128, 416])
 def test_only_y_gamma(tiling):
     """gamma_mask (smoe.py:725-729): slopes act and train only for channel 0."""
     shape, C, kpd = (16, 16), 3, [2, 2]
@@ -550,8 +597,9 @@ def test_only_y_gamma(tiling):
     eng.close()
 
 
+@pytest.mark.parametrize("tiling", [0, 816])
 @pytest.mark.parametrize("qpis", [False, True])
-def test_kernel_count_as_norm_l1(qpis):
+def test_kernel_count_as_norm_l1(qpis, tiling):
     """kernel_count_as_norm_l1 (smoe.py:1022-1027): the pis l1 term is normalised by the number of kernels with
     (q)pis > 0 -- independent of the kernel list -- instead of start_pis."""
     shape, C, kpd = (16, 16), 1, [2, 4]
@@ -564,6 +612,7 @@ def test_kernel_count_as_norm_l1(qpis):
     active = np.ones((B, K), bool)
     active[0, 0] = False
     eng = _engine(shape, C, K, pis_l1=0.3, u_l1=0.002, kernel_count_as_norm_l1=True, quantize_pis=qpis)
+    eng.set_tiling(tiling)
     dp = _to_dev(p)
     act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
     T = _planar(tgt)
