@@ -211,6 +211,14 @@ int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
  * bit-identical for every split of the job into calls / ranks.  0 (the default) = choose from each call's num_blocks. */
 int smoe_set_total_blocks(smoe_handle h, int64_t total_blocks);
 
+/* Pixel sub-sampling (run_batched(train=True, sampling_percentage < 100), smoe.py:1664-1667): the reference feeds a random
+ * subset of a block's pixels.  Here the caller passes the subset as loss weights (N / n for the drawn pixels, 0 for the
+ * others: the same loss and gradients, `mean` over the n drawn pixels).  on != 0 tells the following smoe_fit calls that
+ * their loss_w is such a sample: pixels with weight 0 are "not fed", i.e. they take no part in the influence test that
+ * prunes the kernel list either (smoe.py:829,1763-1766).  With on == 0 (default) weight-0 pixels are loss-mask pixels,
+ * which the reference does feed (smoe.py:1674-1677) and which therefore do vote. */
+int smoe_set_sampling(smoe_handle h, int32_t on);
+
 /* ---------------------------------------------------------------------------------------------
  * Shared-kernel image mode: the reference's whole-image fit.  ONE global set of K
  * kernels over the [0,1]^d image domain; the image is cut into batches (sliding_window,
@@ -268,13 +276,20 @@ int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_b
                         uint32_t* lists, int32_t update_lists, void* stream);
 
 /* run_batched(train=True) minus train_op: forward + tf.gradients of the batches, accumulated into
- * the handle's gradient buffer (accum_ops, smoe.py:1150); kernel lists pruned (smoe.py:1763-1766). */
+ * the handle's gradient buffer (accum_ops, smoe.py:1150); kernel lists pruned (smoe.py:1763-1766).
+ * Summation order: every batch leaves the raw sums of its listed kernels in a row of its own; the buffer is the sum of
+ * the rows of ALL batches accumulated since the last step, per kernel in batch order (fp64) -- bit-identical from run to run
+ * and for any split of a rank's batches over calls.  (Only if the rows would exceed 4 GB -- num_batches x kernels x ~10..22
+ * floats -- the pass falls back to fp64 atomics, whose order is not fixed.) */
 int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
                            const smoe_params* p, float* loss, float* sse, uint32_t* lists, void* stream);
 
 /* train_op (smoe.py:1788): one ApplyAdam step per optimizer group on the accumulated gradients; clears
  * the accumulators (zero_op, smoe.py:1613). */
 int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream);
+
+/* zero_op alone (smoe.py:1613): drop what the smoe_shared_accumulate calls since the last step have accumulated. */
+int smoe_shared_discard(smoe_shared_handle h, void* stream);
 
 /* Device pointer + length (in doubles) of the gradient accumulation buffer. */
 int smoe_shared_grad_buffer(smoe_shared_handle h, double** dev_ptr, int64_t* count);

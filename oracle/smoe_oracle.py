@@ -432,8 +432,12 @@ def ssim_and_grad(q, t, block_shape, T=np.float32, want_grad=False):
 
 def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
             active: np.ndarray, cfg: OracleConfig, loss_w: Optional[np.ndarray] = None,
-            dtype=np.float32, want_grads: bool = False, q_override: Optional[np.ndarray] = None):
+            dtype=np.float32, want_grads: bool = False, q_override: Optional[np.ndarray] = None,
+            fed: Optional[np.ndarray] = None):
     """One pass of the reference graph over B independent blocks.
+
+    ``fed`` (B, N) bool: the pixels a sub-sampled training pass feeds (smoe.py:1664-1667 passes only the drawn rows of
+    ``img_patch``); the kernels that stay on the list are those with influence on a FED pixel (smoe.py:829,1763-1766).
 
     p: parameter dict with leading B.  target: (B, N, C).  coords: (N, d), or (B, N, d) when
     every block/batch has its own pixel coordinates (shared-kernel mode: global domain).
@@ -493,7 +497,7 @@ def forward(p: Dict[str, np.ndarray], target: np.ndarray, coords: np.ndarray,
     M = w > tau                                              # tf.greater: strict
     wt = np.where(M, w, T(0))                                # smoe.py:827
 
-    active_new = np.any(M, axis=2)                           # smoe.py:829,836
+    active_new = np.any(M if fed is None else np.logical_and(M, fed[:, None, :]), axis=2)     # smoe.py:829,836
     # smoe.py:833: argmax over the compacted list, mapped back via indices (1706-1716)
     wt_for_arg = np.where(active_new[:, :, None], wt, T(-1))
     argmax = np.argmax(wt_for_arg, axis=1).astype(np.int64)  # first max

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmoe_hip.so")
+# SMOE_HIP_LIBRARY: another build of the same library (the SMOE_DEBUG one: `make -C csrc debug`), never a different backend
+LIB_PATH = os.environ.get("SMOE_HIP_LIBRARY") or os.path.join(_HERE, "libsmoe_hip.so")
 
 SMOE_ABI_VERSION = 2
 SMOE_OK = 0
@@ -26,7 +27,7 @@ EXPORTS = (
     "smoe_shared_create", "smoe_shared_destroy", "smoe_shared_num_batches", "smoe_shared_list_words",
     "smoe_shared_forward", "smoe_shared_accumulate", "smoe_shared_apply", "smoe_shared_grad_buffer",
     "smoe_shared_fit", "smoe_shared_update_kernel_list", "smoe_shared_set_loss_weights",
-    "smoe_set_center_grid", "smoe_shared_set_center_grid", "smoe_set_total_blocks", "smoe_padded_kernels_full",
+    "smoe_set_center_grid", "smoe_shared_set_center_grid", "smoe_set_total_blocks", "smoe_padded_kernels_full", "smoe_shared_discard", "smoe_set_sampling",
 )
 
 
@@ -108,6 +109,7 @@ def load() -> C.CDLL:
     lib.smoe_fit_occupancy.argtypes = [vp, i32]
     lib.smoe_set_tiling.argtypes = [vp, i32]
     lib.smoe_set_total_blocks.argtypes = [vp, C.c_int64]
+    lib.smoe_set_sampling.argtypes = [vp, i32]
     lib.smoe_last_error.restype = C.c_char_p
     lib.smoe_shared_create.argtypes = [C.POINTER(vp), C.POINTER(SmoeSharedConfig)]
     lib.smoe_shared_destroy.argtypes = [vp]
@@ -120,6 +122,7 @@ def load() -> C.CDLL:
     lib.smoe_shared_fit.argtypes = [vp, fp, C.POINTER(SmoeParams), C.POINTER(SmoeAdamState), i32, fp, fp, fp, vp]
     lib.smoe_shared_update_kernel_list.argtypes = [vp, i32, i32, C.POINTER(SmoeParams), fp, vp]
     lib.smoe_shared_set_loss_weights.argtypes = [vp, fp]
+    lib.smoe_shared_discard.argtypes = [vp, vp]
     lib.smoe_set_center_grid.argtypes = [vp, fp]
     lib.smoe_shared_set_center_grid.argtypes = [vp, fp]
     for name in EXPORTS:

@@ -148,6 +148,24 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #else
 #define SMOE_CLK(i) do { } while (0)
 #endif
+// Debug build (make EXTRA=-DSMOE_DEBUG=1): every kernel compares the end of the LDS carve-up IT will address -- from its own
+// template flags and run-time arguments -- with the dynamic LDS the launcher reserved; a mismatch sets a bit of FitArgs::dbg /
+// FwdArgs::dbg and the workgroup returns before touching LDS (no fault: a faulting kernel can reset the GPUs of the host for
+// everyone on it).  The host layer reads the word after every launch of such a build and fails the call.
+#ifndef SMOE_DEBUG
+#define SMOE_DEBUG 0
+#endif
+#if SMOE_DEBUG
+#define SMOE_LDS_CHECK(end_floats, code)                                                   \
+    do {                                                                                   \
+        if ((long)(end_floats) > (long)a.lds_floats) {                                     \
+            if (threadIdx.x == 0 && a.dbg != nullptr) atomicOr(a.dbg, (uint32_t)(code));   \
+            return;                                                                        \
+        }                                                                                  \
+    } while (0)
+#else
+#define SMOE_LDS_CHECK(end_floats, code) do { } while (0)
+#endif
 #define SMOE_SQ 0.84932180028801904272f
 #define SMOE_INV_SQ 1.17740022503374817543f
 
@@ -423,7 +441,10 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
                                       const float (&x)[D], const float (&t)[C], float lw,
                                       float* __restrict__ acc, PixelOut<D, C, K>& o,
                                       const float* __restrict__ gext = nullptr,
-                                      unsigned long long* __restrict__ flags = nullptr) {
+                                      unsigned long long* __restrict__ flags = nullptr, bool fed = true) {
+    // fed = false: the pixel was not drawn by the sub-sampled pass (smoe.py:1664-1667: the reference feeds the drawn pixels
+    // only), so it takes no part in the influence test that prunes the kernel list (smoe.py:829,1763-1766); its loss weight 0
+    // keeps it out of the loss and of every gradient
     using Lt = Layout<D, C, K>;
     float z[K][D], g[K];
     float S = 0.0f;
@@ -469,8 +490,8 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         w[k] = g[k] * inv;
         const bool infl = w[k] > kc.tau;
         o.wt[k] = infl ? w[k] : 0.0f;
-        if constexpr (FLAGS) flags[k] |= __ballot(infl);
-        else acc[Lt::S_CNT + k] += o.wt[k];
+        if constexpr (FLAGS) flags[k] |= __ballot(infl && fed);
+        else acc[Lt::S_CNT + k] += fed ? o.wt[k] : 0.0f;
         // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -1198,7 +1219,8 @@ template <int D, int C, int K, bool HAS_LW, int HL, bool IC = false>
 __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                                  const float* __restrict__ s_coords, const float* __restrict__ s_tgt,
                                                  const float* __restrict__ s_lw, int N, int G, int sub,
-                                                 float* __restrict__ acc) {
+                                                 float* __restrict__ acc, bool sample = false) {
+    // sample: the loss weights are a pixel sub-sample (FitArgs::lw_is_sample): weight 0 = pixel not fed
     const int pxl = (N + G - 1) / G;
     const int full = N / G;                        // steps in which every lane of the block has a pixel
     unsigned long long flags[K];
@@ -1215,7 +1237,7 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
         for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
         const float lw = HAS_LW ? s_lw[n] : 1.0f;
         PixelOut<D, C, K> o;
-        pixel<D, C, K, true, HL, false, IC, true>(R, kc, x, t, lw, acc, o, nullptr, flags);
+        pixel<D, C, K, true, HL, false, IC, true>(R, kc, x, t, lw, acc, o, nullptr, flags, !(HAS_LW && sample) || lw != 0.0f);
     };
     int i = 0;
     if (full > 0) { step(0); i = 1; }              // peeled: with -fno-signed-zeros the zero initialisation of acc[] folds away
@@ -1237,7 +1259,7 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
             for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
             const float lw = HAS_LW ? s_lw[n] : 1.0f;
             PixelOut<D, C, K> o;
-            pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o);
+            pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o, nullptr, nullptr, !(HAS_LW && sample) || lw != 0.0f);
         }
     }
     const int lane = threadIdx.x & 63;
@@ -1313,6 +1335,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     const float* s_lw = lds + T::off_lw(N, CR) + lb * T::lw_stride(N);
     const bool has_lw = a.loss_w != nullptr;
 
+    SMOE_LDS_CHECK(T::off_ssim(N, has_lw, CR, QUANT) + (SSIM ? T::ssim_tabs(a.bh, a.bw, (D == 3) ? a.bt : 0) + WAVES * T::ssim_wave(N) : 0), 1u);
+    if (owner_post) SMOE_LDS_CHECK(a.desc_off + T::NB * T::DESC_STRIDE, 2u);
     stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds);
     // fake-quantised graph: the quantised parameter image of the block, its mode-3 range records, all-reduce hand-off
     float* s_q = lds + T::off_qimg(N, has_lw, CR) + lb * T::QI_STRIDE;
@@ -1613,7 +1637,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             } else {
                 // PAIR: pixel n = i * 128 + wave * 64 + sub (the hoisted trailing coordinates stay lane constants)
                 const int gl = PAIR ? 2 * G : G, sl = PAIR ? wave * G + sub : sub;
-                if (has_lw) pixel_loop_train<D, C, K, true, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, gl, sl, acc);
+                if (has_lw) pixel_loop_train<D, C, K, true, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, gl, sl, acc, a.lw_is_sample != 0);
                 else pixel_loop_train<D, C, K, false, HL, IC>(R, kc, s_coords, s_tgt, s_lw, N, gl, sl, acc);
             }
             if (HL > 0) complete_const<D, C, K, HL, IC>(R, xc, acc);
@@ -1949,6 +1973,8 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(FwdArgs a) {
             lwr[i] = has_lw ? a.loss_w[(size_t)b * N + n] : 1.0f;
         }
     }
+    SMOE_LDS_CHECK(regt ? T::off_tgt(N, CR)
+                        : T::off_ssim(N, has_lw, CR) + (SSIM ? T::ssim_tabs(a.bh, a.bw, (D == 3) ? a.bt : 0) + WAVES * T::ssim_wave(N) : 0), 4u);
     stage_inputs<D, C, K, G, WAVES, CR>(a.coords, a.target, a.loss_w, B, N, blk0, lds, !regt);
     float* s_ssim = lds + T::off_ssim(N, has_lw, CR);
     const int bh = a.bh, bw = a.bw, bt = (D == 3) ? a.bt : 0;
@@ -2318,6 +2344,7 @@ hipError_t launch_fit(const FitArgs& a, int hoist, hipStream_t st) {
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + nb - 1) / nb;
+    aa.lds_floats = (int)(shm_all / sizeof(float));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }
@@ -2343,6 +2370,7 @@ hipError_t launch_fwd(const FwdArgs& a, hipStream_t st) {
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
+    aa.lds_floats = (int)(shm / sizeof(float));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
     return hipGetLastError();
 }
@@ -2367,6 +2395,7 @@ hipError_t launch_fit_quant(const FitArgs& a, int hoist, hipStream_t st) {
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
+    aa.lds_floats = (int)(shm_all / sizeof(float));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }
@@ -2384,6 +2413,7 @@ hipError_t launch_fwd_quant(const FwdArgs& a, hipStream_t st) {
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
+    aa.lds_floats = (int)(shm / sizeof(float));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
     return hipGetLastError();
 }
@@ -2405,6 +2435,7 @@ hipError_t launch_fit_ic(const FitArgs& a, int hoist, hipStream_t st) {
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
+    aa.lds_floats = (int)(shm_all / sizeof(float));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
     return hipGetLastError();
 }
@@ -2422,6 +2453,7 @@ hipError_t launch_fwd_ic(const FwdArgs& a, hipStream_t st) {
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + T::NB - 1) / T::NB;
+    aa.lds_floats = (int)(shm / sizeof(float));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
     return hipGetLastError();
 }
@@ -2451,7 +2483,8 @@ hipError_t launch_fit_ssim(const FitArgs& a, int hoist, hipStream_t st) {
         hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm_all);
         if (e != hipSuccess) return e;
         const int grid = (a.B + T::NB - 1) / T::NB;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
+        aa.lds_floats = (int)(shm_all / sizeof(float));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm_all, st, aa);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;
@@ -2472,7 +2505,8 @@ hipError_t launch_fwd_ssim(const FwdArgs& a, hipStream_t st) {
         const int grid = (a.B + T::NB - 1) / T::NB;
         FwdArgs aa = a;
         aa.regt = 0;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
+        aa.lds_floats = (int)(shm / sizeof(float));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::THREADS), shm, st, aa);
         return hipGetLastError();
     } else {
         return hipErrorNotSupported;

@@ -19,6 +19,7 @@ struct smoe_context {
     float* d_probes;     // [D][3]
     float* d_ssim_T;     // ssim_opt: banded tap tables Tr [bh][11], Tc [bw][11]
     double* d_partials;  // workspace of smoe_reduce_scalars
+    uint32_t* d_dbg;     // SMOE_DEBUG build: word the kernels' device-side checks report into (null otherwise)
     int force_g;
     const float* mus_grid;   // use_diff_center: kernel-grid centres [B,K,D] of the blocks the calls pass (smoe_set_center_grid), or null
     mutable int big_g;   // lanes per block for blocks of more than 512 pixels (big_block_lanes; -1: not asked yet)
@@ -26,6 +27,8 @@ struct smoe_context {
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     long long total_blocks;   // smoe_set_total_blocks: block count of the whole job the calls are shards of (0: each call's own)
     int force_team;      // 0: by batch size, 2 / 4 / 8: team tiling with that many wavefronts per workgroup, -1: never
+    int lw_is_sample;    // smoe_set_sampling: the loss_w of smoe_fit is a pixel sub-sample
+    int simds;           // SIMDs of the device (4 per CU; 1 024 on MI355X): the batch-size thresholds of the tiling rules scale with it
     std::string variant_name;   // what smoe_fit_variant last returned (the team names are composed)
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
@@ -72,8 +75,8 @@ hipError_t dev_zero(void* d, size_t n) { std::memset(d, 0, n); return hipSuccess
 void dev_free(void* p) { std::free(p); }
 #else
 template <typename T> hipError_t dev_malloc(T** p, size_t n) { return hipMalloc(p, n); }
-hipError_t dev_upload(void* d, const void* src, size_t n) { return dev_upload(d, src, n); }
-hipError_t dev_download(void* d, const void* src, size_t n) { return dev_download(d, src, n); }
+hipError_t dev_upload(void* d, const void* src, size_t n) { return hipMemcpy(d, src, n, hipMemcpyHostToDevice); }
+hipError_t dev_download(void* d, const void* src, size_t n) { return hipMemcpy(d, src, n, hipMemcpyDeviceToHost); }
 hipError_t dev_zero(void* d, size_t n) { return hipMemset(d, 0, n); }
 void dev_free(void* p) { (void)hipFree(p); }
 #endif
@@ -200,11 +203,14 @@ int choice_blocks(const smoe_context* h, int num_blocks) {
     return (h->total_blocks > 0x7fffffffLL) ? 0x7fffffff : (int)h->total_blocks;
 }
 
+// The thresholds were measured on MI355X (256 CUs = 1 024 SIMDs) and are kept as blocks PER SIMD, so that a part with another
+// CU count (or a partitioned one) moves them with it: what decides is how many wavefronts each SIMD gets to interleave.
 int wanted_lanes(const smoe_context* h, int num_blocks) {
     if (h->force_g) return h->force_g;
-    if (h->N > 512) return (num_blocks >= 1536) ? big_block_lanes(h) : 64;     // fewer: 32 lanes would leave SIMDs without a wavefront
-    if (num_blocks >= 8192) return 16;      // 8 192 blocks: 276 (16 lanes) vs 213 (32) Gpx-it/s
-    if (num_blocks >= 3072) return 32;      // 4 096 blocks: 208 (32) vs 177 (16) vs 157 (64); 2 048 blocks: 2 wavefronts per SIMD on 64 lanes win
+    const long s = h->simds;
+    if (h->N > 512) return (2L * num_blocks >= 3 * s) ? big_block_lanes(h) : 64;     // < 1.5 per SIMD: 32 lanes would leave SIMDs without a wavefront
+    if (num_blocks >= 8 * s) return 16;     // 8 192 blocks: 276 (16 lanes) vs 213 (32) Gpx-it/s
+    if (num_blocks >= 3 * s) return 32;     // 4 096 blocks: 208 (32) vs 177 (16) vs 157 (64); 2 048 blocks: 2 wavefronts per SIMD on 64 lanes win
     return 64;
 }
 
@@ -220,9 +226,30 @@ bool wants_pair(smoe_context* h, const smoe::Variant* v, int num_blocks) {
     if (v->G != 64 || v->W != 2 || h->N < 128) return false;
     if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov) return false;
     if (h->force_pair) return h->force_pair > 0;
-    if (choice_blocks(h, num_blocks) > PAIR_MAX_BLOCKS) return false;
+    if (choice_blocks(h, num_blocks) > (long)PAIR_MAX_BLOCKS * h->simds / 1024) return false;     // at most one block per SIMD
     if (h->pair_occ < 0) h->pair_occ = v->fit_waves_per_cu(h->N, false, hoist_level(h, v), true);   // of the PAIR kernel itself
     return h->pair_occ >= 8;                                   // two wavefronts per SIMD can be resident together
+}
+
+// SMOE_DEBUG build (make EXTRA=-DSMOE_DEBUG=1): the kernels report failed device-side checks (LDS carve-up vs the dynamic LDS of
+// the launch) into h->d_dbg; the call waits for its launch and fails if a bit is set.
+#ifndef SMOE_DEBUG
+#define SMOE_DEBUG 0
+#endif
+int check_debug_word(smoe_context* h, hipStream_t st, const char* who) {
+#if SMOE_DEBUG && !SMOE_HOST_TEST
+    uint32_t w = 0;
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&w, h->d_dbg, sizeof w, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(SMOE_ERR_HIP, std::string(who) + ": SMOE_DEBUG read-back failed");
+    if (w != 0) {
+        (void)hipMemset(h->d_dbg, 0, sizeof w);
+        return fail(SMOE_ERR_HIP, std::string(who) + ": SMOE_DEBUG device check failed (the kernel's LDS carve-up exceeds the dynamic LDS of "
+                                  "the launch), code " + std::to_string(w));
+    }
+#else
+    (void)h; (void)st; (void)who;
+#endif
+    return SMOE_OK;
 }
 
 // Team tiling (smoe_team.hip.h): four blocks per workgroup on the 16-lane layout, the workgroup's wavefronts split the pixel
@@ -363,6 +390,14 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->force_g = 0;
     h->force_pair = 0;
     h->force_team = 0;
+    h->lw_is_sample = 0;
+    h->simds = 1024;
+#if !SMOE_HOST_TEST
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->simds = 4 * cus;
+    }
+#endif
     h->total_blocks = 0;
     h->pair_occ = -1;
     h->big_g = -1;
@@ -371,6 +406,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->d_probes = nullptr;
     h->d_ssim_T = nullptr;
     h->d_partials = nullptr;
+    h->d_dbg = nullptr;
     const int D = cfg->dim;
 
     // per-pixel coordinates [D][N], 'ij' meshgrid flattened row-major (smoe.py:2418-2421,1650)
@@ -398,6 +434,10 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     if (e == hipSuccess) e = dev_upload(h->d_coords, h->h_coords.data(), sizeof(float) * D * N);
     if (e == hipSuccess) e = dev_upload(h->d_probes, probes.data(), sizeof(float) * D * 3);
     if (e == hipSuccess) e = dev_malloc(&h->d_partials, sizeof(double) * smoe::reduce_partials_count());
+#if SMOE_DEBUG
+    if (e == hipSuccess) e = dev_malloc(&h->d_dbg, sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_zero(h->d_dbg, sizeof(uint32_t));
+#endif
     if (e == hipSuccess && cfg->ssim_opt) {
         const int bh = cfg->block_shape[0], bw = cfg->block_shape[1], bt = (cfg->dim == 3) ? cfg->block_shape[2] : 0;
         std::vector<float> tabs((size_t)11 * (bh + bw + bt));
@@ -412,6 +452,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
         if (h->d_probes) dev_free(h->d_probes);
         if (h->d_ssim_T) dev_free(h->d_ssim_T);
         if (h->d_partials) dev_free(h->d_partials);
+        if (h->d_dbg) dev_free(h->d_dbg);
         delete h;
         return fail_hip(e, "smoe_create: workspace");
     }
@@ -475,6 +516,7 @@ int smoe_destroy(smoe_handle h) {
     if (h->d_probes) dev_free(h->d_probes);
     if (h->d_ssim_T) dev_free(h->d_ssim_T);
     if (h->d_partials) dev_free(h->d_partials);
+    if (h->d_dbg) dev_free(h->d_dbg);
     delete h;
     return SMOE_OK;
 }
@@ -504,6 +546,12 @@ int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     h->force_g = (lanes_per_block == 128) ? 64 : (team ? 0 : lanes_per_block);
     h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0 || team) ? 0 : -1);
     h->force_team = team ? lanes_per_block / 100 : ((lanes_per_block == 0) ? 0 : -1);
+    return SMOE_OK;
+}
+
+int smoe_set_sampling(smoe_handle h, int32_t on) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_sampling: null handle");
+    h->lw_is_sample = on ? 1 : 0;
     return SMOE_OK;
 }
 
@@ -560,11 +608,12 @@ int smoe_forward(smoe_handle h, int32_t num_blocks, const float* target, const f
     a.kc = h->kc;
     a.ssim_T = h->d_ssim_T; a.bh = h->cfg.block_shape[0]; a.bw = h->cfg.block_shape[1]; a.bt = h->cfg.block_shape[2];
     a.mus_grid = h->mus_grid;
+    a.lds_floats = 0; a.dbg = h->d_dbg;
     if (h->cfg.ssim_opt) HIP_TRY(v->fwd_ssim(a, (hipStream_t)stream), "smoe_forward (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fwd_quant(a, (hipStream_t)stream), "smoe_forward (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fwd_ic(a, (hipStream_t)stream), "smoe_forward (inverse covariance) launch");
     else HIP_TRY(v->fwd(a, (hipStream_t)stream), "smoe_forward launch");
-    return SMOE_OK;
+    return check_debug_word(h, (hipStream_t)stream, "smoe_forward");
 }
 
 int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float* loss_w,
@@ -592,9 +641,12 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.reg_u = c.u_l1;
     a.kc = h->kc;
     const int hoist = hoist_level(h, v);
+    (void)hoist;
     a.ssim_T = h->d_ssim_T; a.bh = c.block_shape[0]; a.bw = c.block_shape[1]; a.bt = c.block_shape[2];
     a.pair = wants_pair(h, v, num_blocks) ? 1 : 0;
     a.mus_grid = h->mus_grid;
+    a.lds_floats = 0; a.dbg = h->d_dbg; a.desc_off = 0;
+    a.lw_is_sample = (h->lw_is_sample && loss_w != nullptr && !c.ssim_opt) ? 1 : 0;
     const smoe::Variant* v16 = nullptr;
     const int team = team_waves(h, num_blocks, loss_w != nullptr, &v16);
     if (team > 0) HIP_TRY(v16->fit_team(a, hoist_level(h, v16), team, (hipStream_t)stream), "smoe_fit (team) launch");
@@ -608,7 +660,7 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
         s->beta2_power *= c.beta2;
     }
     s->step += n_iters;
-    return SMOE_OK;
+    return check_debug_word(h, (hipStream_t)stream, "smoe_fit");
 }
 
 int smoe_update_kernel_list(smoe_handle h, int32_t num_blocks, const smoe_params* p,
@@ -671,6 +723,12 @@ struct smoe_shared_context {
     float* d_axes;        // concatenated per-axis coordinate tables
     float* d_probes;      // [NB][D][3]
     double* d_racc;       // [K*PK + K]
+    // fixed-order gradient accumulation (SharedGatherArgs): per-batch rows of raw sums, the kernels each batch trained, the
+    // pass number a row belongs to; null when the rows would not fit (then fp64 atomics, not bit-deterministic)
+    float* d_part;        // [NB][K][PK]
+    uint32_t* d_trained;  // [NB][KW]
+    uint32_t* d_batch_epoch;  // [NB]
+    uint32_t epoch;       // current pass (bumped by smoe_shared_apply)
     float* d_ssim_T;      // ssim_opt: banded tap tables of the batch shape
     float* d_qrng;        // SharedRangesArgs records (mode-3 ranges, count of qpis > 0)
     bool need_ranges;     // quantization_mode 3 or kernel_count_as_norm_l1
@@ -703,6 +761,13 @@ void fill_shared_args(const smoe_shared_context* h, smoe::SharedArgs& a) {
     a.nact = h->d_racc + (size_t)c.kernels * h->PK;
     a.qrng = h->d_qrng;
     a.mus_grid = h->mus_grid;
+    a.part = h->d_part; a.trained = h->d_trained; a.batch_epoch = h->d_batch_epoch; a.epoch = h->epoch;
+}
+
+void fill_gather_args(const smoe_shared_context* h, smoe::SharedGatherArgs& g) {
+    g.part = h->d_part; g.trained = h->d_trained; g.batch_epoch = h->d_batch_epoch; g.epoch = h->epoch;
+    g.NB_total = h->NB; g.K = h->cfg.kernels; g.KW = h->KW; g.PK = h->PK;
+    g.racc = h->d_racc; g.nact = h->d_racc + (size_t)h->cfg.kernels * h->PK;
 }
 
 // the image-wide records follow the parameters of THIS call (the C ABI is stateless in the parameters)
@@ -805,6 +870,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     }
     const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
     h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->d_qrng = nullptr; h->loss_w = nullptr; h->mus_grid = nullptr;
+    h->d_part = nullptr; h->d_trained = nullptr; h->d_batch_epoch = nullptr; h->epoch = 1u;
     h->need_ranges = cfg->quantization_mode == 3 || cfg->kernel_count_as_norm_l1 != 0;
     if (cfg->ssim_opt) {
         const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
@@ -820,6 +886,17 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     if (e == hipSuccess) e = dev_upload(h->d_axes, axes.data(), sizeof(float) * axes.size());
     if (e == hipSuccess) e = dev_upload(h->d_probes, probes.data(), sizeof(float) * probes.size());
     if (e == hipSuccess) e = dev_zero(h->d_racc, sizeof(double) * nacc);
+    {
+        // one row of raw sums per (batch, kernel): 512x512 / 32x32 batches / 144 kernels = 1.3 MB; 2048x2048 / 2304 kernels =
+        // 340 MB.  Beyond 4 GB the rows are not allocated and the pass falls back to fp64 atomics.
+        const size_t rows = (size_t)NB * (size_t)cfg->kernels * (size_t)h->PK;
+        if (rows * sizeof(float) <= ((size_t)4 << 30)) {
+            if (e == hipSuccess) e = dev_malloc(&h->d_part, sizeof(float) * rows);
+            if (e == hipSuccess) e = dev_malloc(&h->d_trained, sizeof(uint32_t) * (size_t)NB * KW);
+            if (e == hipSuccess) e = dev_malloc(&h->d_batch_epoch, sizeof(uint32_t) * (size_t)NB);
+            if (e == hipSuccess) e = dev_zero(h->d_batch_epoch, sizeof(uint32_t) * (size_t)NB);
+        }
+    }
     if (e == hipSuccess) e = dev_malloc(&h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess) e = dev_zero(h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess && cfg->ssim_opt) {
@@ -837,6 +914,9 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         if (h->d_racc) dev_free(h->d_racc);
         if (h->d_ssim_T) dev_free(h->d_ssim_T);
         if (h->d_qrng) dev_free(h->d_qrng);
+        if (h->d_part) dev_free(h->d_part);
+        if (h->d_trained) dev_free(h->d_trained);
+        if (h->d_batch_epoch) dev_free(h->d_batch_epoch);
         delete h;
         return fail_hip(e, "smoe_shared_create: workspace");
     }
@@ -883,6 +963,9 @@ int smoe_shared_destroy(smoe_shared_handle h) {
     if (h->d_racc) dev_free(h->d_racc);
     if (h->d_ssim_T) dev_free(h->d_ssim_T);
     if (h->d_qrng) dev_free(h->d_qrng);
+    if (h->d_part) dev_free(h->d_part);
+    if (h->d_trained) dev_free(h->d_trained);
+    if (h->d_batch_epoch) dev_free(h->d_batch_epoch);
     delete h;
     return SMOE_OK;
 }
@@ -927,8 +1010,10 @@ int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_b
     return SMOE_OK;
 }
 
-int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
-                           const smoe_params* p, float* loss, float* sse, uint32_t* lists, void* stream) {
+// gather: sum the batches' rows into the gradient buffer right away (what smoe_shared_grad_buffer hands out for the
+// all-reduce); smoe_shared_fit leaves it to the step kernel (one launch less per iteration)
+static int shared_accumulate_impl(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
+                                  const smoe_params* p, float* loss, float* sse, uint32_t* lists, void* stream, bool gather) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_accumulate: null handle");
     int rc = check_range(h, first_batch, num_batches, "smoe_shared_accumulate");
     if (rc) return rc;
@@ -941,10 +1026,15 @@ int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t nu
     a.loss = loss; a.sse = sse; a.recon = nullptr; a.argmax = nullptr; a.update_lists = 1;
     HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_accumulate ranges");
     HIP_TRY(smoe::launch_shared_pass(a, h->cfg.dim, h->cfg.channels, true, (hipStream_t)stream), "smoe_shared_accumulate launch");
+    if (gather && h->d_part != nullptr) {
+        smoe::SharedGatherArgs g;
+        fill_gather_args(h, g);
+        HIP_TRY(smoe::launch_shared_gather(g, (hipStream_t)stream), "smoe_shared_accumulate gather");
+    }
     return SMOE_OK;
 }
 
-int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream) {
+static int shared_apply_impl(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream, bool gather) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: null handle");
     if (!params_ok(p) || !s || !params_ok(&s->m) || !params_ok(&s->v)) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: params and adam state are required");
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
@@ -961,11 +1051,38 @@ int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, 
     a.reg_u = c.u_l1;
     a.qrng = h->d_qrng;
     a.mus_grid = h->mus_grid;
+    fill_gather_args(h, a.gather);
+    const bool fused = gather && h->d_part != nullptr && h->kc.qmode != 3;      // the mode-3 step is ONE workgroup over all kernels
+    if (gather && h->d_part != nullptr && !fused)
+        HIP_TRY(smoe::launch_shared_gather(a.gather, (hipStream_t)stream), "smoe_shared_apply gather");
+    if (!fused) a.gather.part = nullptr;
     HIP_TRY(refresh_ranges(h, p, (hipStream_t)stream), "smoe_shared_apply ranges");
     HIP_TRY(smoe::launch_shared_adam(a, c.dim, c.channels, (hipStream_t)stream), "smoe_shared_apply launch");
     s->beta1_power *= c.beta1;
     s->beta2_power *= c.beta2;
     s->step += 1;
+    h->epoch += 1u;                                   // the rows of this pass are spent
+    if (h->epoch == 0u) h->epoch = 1u;
+    return SMOE_OK;
+}
+
+int smoe_shared_accumulate(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
+                           const smoe_params* p, float* loss, float* sse, uint32_t* lists, void* stream) {
+    return shared_accumulate_impl(h, first_batch, num_batches, target, p, loss, sse, lists, stream, true);
+}
+
+int smoe_shared_apply(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream) {
+    return shared_apply_impl(h, p, s, stream, false);
+}
+
+int smoe_shared_discard(smoe_shared_handle h, void* stream) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_discard: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+    const size_t nacc = (size_t)h->cfg.kernels * h->PK + h->cfg.kernels;
+    (void)nacc;
+    HIP_TRY(hipMemsetAsync(h->d_racc, 0, sizeof(double) * nacc, (hipStream_t)stream), "smoe_shared_discard");
+    h->epoch += 1u;
+    if (h->epoch == 0u) h->epoch = 1u;
     return SMOE_OK;
 }
 
@@ -974,9 +1091,9 @@ int smoe_shared_fit(smoe_shared_handle h, const float* target, smoe_params* p, s
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_fit: null handle");
     if (n_iters < 0) return fail(SMOE_ERR_INVALID, "smoe_shared_fit: negative n_iters");
     for (int i = 0; i < n_iters; ++i) {
-        int rc = smoe_shared_accumulate(h, 0, h->NB, target, p, loss_last, sse_last, lists, stream);
+        int rc = shared_accumulate_impl(h, 0, h->NB, target, p, loss_last, sse_last, lists, stream, false);
         if (rc) return rc;
-        rc = smoe_shared_apply(h, p, s, stream);
+        rc = shared_apply_impl(h, p, s, stream, true);
         if (rc) return rc;
     }
     return SMOE_OK;

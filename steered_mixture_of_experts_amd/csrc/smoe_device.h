@@ -59,6 +59,9 @@ struct FitArgs {
     int desc_off;             // float offset of the owner-side gradient descriptors in the dynamic LDS (set by the launcher; 0 = off)
     const float* mus_grid;    // use_diff_center with quantization_mode 2 / 3: kernel-grid centres [B,K,D] (null otherwise)
     int pair;                 // few blocks: one block per 2-wavefront workgroup (64-lane tiling, margin loss; fit_kernel PAIR)
+    int lds_floats;           // dynamic LDS of the launch in floats (set by the launcher; read by the SMOE_DEBUG carve-up checks)
+    uint32_t* dbg;            // SMOE_DEBUG build: device word that collects failed device-side checks (null otherwise)
+    int lw_is_sample;         // loss_w is a pixel sub-sample (smoe_set_sampling): weight-0 pixels are not fed, they do not vote in the kernel-list prune
     KernelConsts kc;
 };
 
@@ -80,6 +83,8 @@ struct FwdArgs {
     float reg_pi, reg_u;
     const float* ssim_T;
     int bh, bw, bt;
+    int lds_floats;           // as in FitArgs
+    uint32_t* dbg;
     KernelConsts kc;
 };
 
@@ -156,6 +161,26 @@ struct SharedArgs {
     int ssim_off;             // float offset of the SSIM planes inside the workgroup's LDS
     const float* qrng;        // image-wide records of shared_ranges_kernel (mode 3 ranges, count of qpis > 0); see SharedRangesArgs
     const float* mus_grid;    // use_diff_center with quantization_mode 2 / 3: kernel-grid centres [K][D] (null otherwise)
+    // fixed-order gradient accumulation (train passes): every batch leaves the raw sums of its listed kernels in its own rows
+    // part[global batch][kernel][PK] and the set of those kernels in trained[global batch][KW], stamped with the pass number
+    // (batch_epoch); SharedGatherArgs sums them per kernel in batch order.  part == null: fp64 atomics into racc / nact.
+    float* part;
+    uint32_t* trained;
+    uint32_t* batch_epoch;
+    uint32_t epoch;
+};
+
+// Per-kernel sum over the batches of the current pass, in a fixed order (lane = batch mod 64 ascending, then a butterfly
+// over the lanes): racc[k][PK] and nact[k] are OVERWRITTEN -- bit-identical from run to run and for every split of the
+// batches of a rank over smoe_shared_accumulate calls.
+struct SharedGatherArgs {
+    const float* part;
+    const uint32_t* trained;
+    const uint32_t* batch_epoch;
+    uint32_t epoch;
+    int NB_total, K, KW, PK;
+    double* racc;
+    double* nact;
 };
 
 struct SharedAdamArgs {
@@ -170,6 +195,7 @@ struct SharedAdamArgs {
     KernelConsts kc;          // fake quant of the variables (quantize_pis, quantization_mode 2 / 3)
     float* qrng;              // records of shared_ranges_kernel for the CURRENT parameters (mode 3, kernel_count_as_norm_l1)
     const float* mus_grid;    // as in SharedArgs
+    SharedGatherArgs gather;  // gather.part != null: the step sums the batches' rows itself (single launch per step, smoe_shared_fit)
 };
 
 struct SharedReadmitArgs {
@@ -200,6 +226,7 @@ size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw, int bt);
 bool shared_supported(int D, int C, int Nb);
 hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st);
 hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st);
+hipError_t launch_shared_gather(const SharedGatherArgs& g, hipStream_t st);
 hipError_t launch_shared_readmit(const SharedReadmitArgs& a, int D, hipStream_t st);
 hipError_t launch_shared_ranges(const SharedRangesArgs& a, int D, int C, hipStream_t st);
 

@@ -148,40 +148,35 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_cnt + 8);       // [KW]
 
     // ---- 0. compact the batch's kernel list: listed & pis > 0 (smoe.py:480,738) ----------------
-    // one thread per 32-bit word of the bitmap (the lists are sparse: only the listed kernels' priors are read), ascending
-    // kernel ids: exclusive prefix of the per-word counts inside the wavefront by DPP, across wavefronts through LDS
+    // one thread per KERNEL (256 per round): its list bit, and -- only if listed -- its prior, all loads of a round in flight
+    // together (one thread per bitmap word walked its up to 32 listed kernels with one dependent global load each: the dense
+    // lists of the first passes cost tens of microseconds); ascending kernel ids: position = kernels kept by the wavefronts
+    // before + lanes before (ballot)
     const uint32_t* bits = a.lists + (size_t)b * a.KW;
     if (tid == 0) s_cnt[0] = 0;
     __syncthreads();
-    for (int base = 0; base < a.KW; base += SH_THREADS) {
-        const int w = base + tid;
-        uint32_t keep = 0u;
-        if (w < a.KW) {
-            uint32_t word = bits[w];
-            if (w == a.KW - 1 && (K & 31)) word &= (1u << (K & 31)) - 1u;
-            while (word) {
-                const int j = __ffs(word) - 1;
-                word &= word - 1u;
-                if (fqv(a.p.pis[w * 32 + j], a.kc, 3) > 0.0f) keep |= 1u << j;
-            }
+    for (int kbase = 0; kbase < K; kbase += SH_THREADS) {
+        const int k = kbase + tid;
+        bool keep = false;
+        if (k < K && ((bits[k >> 5] >> (k & 31)) & 1u)) keep = fqv(a.p.pis[k], a.kc, 3) > 0.0f;
+        const unsigned long long m = __ballot(keep);
+        if (TRAIN && a.trained != nullptr && lane == 0) {                   // the kernels this pass trains here (gather step)
+            const int w0 = (kbase + wave * 64) >> 5;
+            if (w0 < a.KW) a.trained[(size_t)(a.b0 + b) * a.KW + w0] = (uint32_t)m;
+            if (w0 + 1 < a.KW) a.trained[(size_t)(a.b0 + b) * a.KW + w0 + 1] = (uint32_t)(m >> 32);
         }
-        const int cnt = __popc(keep);
-        const int incl = wave_scan(cnt);
-        if (lane == 63) s_cnt[1 + wave] = incl;
+        if (lane == 0) s_cnt[1 + wave] = __popcll(m);
         __syncthreads();
-        int off = s_cnt[0] + incl - cnt;
+        int off = s_cnt[0];
         for (int ww = 0; ww < wave; ++ww) off += s_cnt[1 + ww];
-        while (keep) {
-            const int j = __ffs(keep) - 1;
-            keep &= keep - 1u;
-            s_list[off++] = w * 32 + j;
-        }
+        if (keep) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = k;
         __syncthreads();
         if (tid == 0) s_cnt[0] += s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4];
         __syncthreads();
     }
     const int Kact = s_cnt[0];
     for (int i = tid; i < Kact; i += SH_THREADS) s_flag[i] = 0;
+    if (TRAIN && a.batch_epoch != nullptr && tid == 0) a.batch_epoch[a.b0 + b] = a.epoch;
 
     // ---- 1. this lane's pixels: global coordinates (smoe.py:2412) and targets --------------------
     int bo[D];                       // batch origin per axis (sliding_window order: last axis fastest)
@@ -535,9 +530,12 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                 const int kk = i / L::PK;
                 const int j = i - kk * L::PK;
                 const float v = (s_acc[i] + s_acc[SH_KC * L::PK + i]) + (s_acc[2 * SH_KC * L::PK + i] + s_acc[3 * SH_KC * L::PK + i]);
-                atomicAdd(&a.racc[(size_t)s_list[c0 + kk] * L::PK + j], (double)v);
+                // the batch's own row of the partial buffer (summed per kernel in batch order by the gather step: fixed order,
+                // bit-deterministic); without the buffer: fp64 atomics, whose order varies from run to run
+                if (a.part != nullptr) a.part[((size_t)(a.b0 + b) * K + s_list[c0 + kk]) * L::PK + j] = v;
+                else atomicAdd(&a.racc[(size_t)s_list[c0 + kk] * L::PK + j], (double)v);
             }
-            if (a.nact != nullptr)
+            if (a.part == nullptr && a.nact != nullptr)
                 for (int i = tid; i < n; i += SH_THREADS) atomicAdd(&a.nact[s_list[c0 + i]], 1.0);
         }
     }
@@ -601,6 +599,45 @@ struct KernelStep {
     float g_pi, g_mu[D], g_A[D][D], g_nu[C], g_ga[D * C];
 };
 
+// Sum of the batches' rows of kernel k over the current pass, by the 64 lanes of a wavefront: lane l takes the batches
+// l, l + 64, ... in ascending order (fp64), then a butterfly over the lanes -- a fixed order.  Every lane returns the totals.
+template <int PK>
+__device__ __forceinline__ void gather_kernel_sums(const SharedGatherArgs& g, int k, int lane, double (&s)[PK], double& cnt) {
+#pragma unroll
+    for (int j = 0; j < PK; ++j) s[j] = 0.0;
+    cnt = 0.0;
+    const int w = k >> 5;
+    const uint32_t bit = 1u << (k & 31);
+    for (int b = lane; b < g.NB_total; b += 64) {
+        if (g.batch_epoch[b] != g.epoch || !(g.trained[(size_t)b * g.KW + w] & bit)) continue;
+        const float* row = g.part + ((size_t)b * g.K + k) * PK;
+#pragma unroll
+        for (int j = 0; j < PK; ++j) s[j] += (double)row[j];
+        cnt += 1.0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < PK; ++j) s[j] += __shfl_xor(s[j], off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+}
+
+template <int PK>
+__global__ void __launch_bounds__(64) shared_gather_kernel(SharedGatherArgs g) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    double s[PK], cnt;
+    gather_kernel_sums<PK>(g, k, lane, s, cnt);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < PK; ++j) g.racc[(size_t)k * PK + j] = s[j];
+        g.nact[k] = cnt;
+    }
+}
+
+template <int D, int C>
+__device__ __forceinline__ void kernel_step_from(const SharedAdamArgs& a, int k, const float (&r)[SL<D, C>::PK], float nact, KernelStep<D, C>& S);
+
 template <int D, int C>
 __device__ __forceinline__ void kernel_step(const SharedAdamArgs& a, int k, bool clear, KernelStep<D, C>& S) {
     using L = SL<D, C>;
@@ -610,6 +647,12 @@ __device__ __forceinline__ void kernel_step(const SharedAdamArgs& a, int k, bool
     for (int j = 0; j < L::PK; ++j) { r[j] = (float)rk[j]; if (clear) rk[j] = 0.0; }
     const float nact = a.nact ? (float)a.nact[k] : 0.0f;
     if (a.nact && clear) a.nact[k] = 0.0;
+    kernel_step_from<D, C>(a, k, r, nact, S);
+}
+
+template <int D, int C>
+__device__ __forceinline__ void kernel_step_from(const SharedAdamArgs& a, int k, const float (&r)[SL<D, C>::PK], float nact, KernelStep<D, C>& S) {
+    using L = SL<D, C>;
     S.pi_raw = a.p.pis[k];
     S.pi = fqv(S.pi_raw, a.kc, 3);
 #pragma unroll
@@ -712,12 +755,26 @@ __device__ __forceinline__ void kernel_apply(const SharedAdamArgs& a, int k, Ker
 
 // quantization_mode 0 / 1 / 2 and quantize_pis: the fake-quant backward is a per-element mask (straight through inside
 // the nudged range), kernels are independent
+// One wavefront per kernel.  a.gather.part != null: the wavefront first sums the batches' rows of its kernel (fixed order);
+// lane 0 then takes the step.
 template <int D, int C>
-__global__ void shared_adam_kernel(SharedAdamArgs a) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.K) return;
+__global__ void __launch_bounds__(64) shared_adam_kernel(SharedAdamArgs a) {
+    using L = SL<D, C>;
+    const int k = blockIdx.x, lane = threadIdx.x;
     KernelStep<D, C> S;
-    kernel_step<D, C>(a, k, true, S);
+    if (a.gather.part != nullptr) {
+        double s[L::PK], cnt;
+        gather_kernel_sums<L::PK>(a.gather, k, lane, s, cnt);
+        if (lane != 0) return;
+        float r[L::PK];
+#pragma unroll
+        for (int j = 0; j < L::PK; ++j) { r[j] = (float)s[j]; a.racc[(size_t)k * L::PK + j] = 0.0; }
+        if (a.nact) a.nact[k] = 0.0;
+        kernel_step_from<D, C>(a, k, r, (float)cnt, S);
+    } else {
+        if (lane != 0) return;
+        kernel_step<D, C>(a, k, true, S);
+    }
     S.g_pi = fq_pass(S.pi_raw, a.kc, 3) ? S.g_pi : 0.0f;
 #pragma unroll
     for (int l = 0; l < D; ++l) {
@@ -988,12 +1045,22 @@ hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    const int threads = 128;
-    const int grid = (a.K + threads - 1) / threads;
+    const int threads = 64;
+    const int grid = a.K;                              // one wavefront per kernel
     if (D == 2 && C == 1) hipLaunchKernelGGL((shared_adam_kernel<2, 1>), dim3(grid), dim3(threads), 0, st, a);
     else if (D == 2 && C == 3) hipLaunchKernelGGL((shared_adam_kernel<2, 3>), dim3(grid), dim3(threads), 0, st, a);
     else if (D == 3 && C == 1) hipLaunchKernelGGL((shared_adam_kernel<3, 1>), dim3(grid), dim3(threads), 0, st, a);
     else if (D == 3 && C == 3) hipLaunchKernelGGL((shared_adam_kernel<3, 3>), dim3(grid), dim3(threads), 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_shared_gather(const SharedGatherArgs& g, hipStream_t st) {
+    // PK = 1 + D + D (D + 1) / 2 + C + D C for (D, C) in {2, 3} x {1, 3}
+    if (g.PK == SL<2, 1>::PK) hipLaunchKernelGGL((shared_gather_kernel<SL<2, 1>::PK>), dim3(g.K), dim3(64), 0, st, g);
+    else if (g.PK == SL<2, 3>::PK) hipLaunchKernelGGL((shared_gather_kernel<SL<2, 3>::PK>), dim3(g.K), dim3(64), 0, st, g);
+    else if (g.PK == SL<3, 1>::PK) hipLaunchKernelGGL((shared_gather_kernel<SL<3, 1>::PK>), dim3(g.K), dim3(64), 0, st, g);
+    else if (g.PK == SL<3, 3>::PK) hipLaunchKernelGGL((shared_gather_kernel<SL<3, 3>::PK>), dim3(g.K), dim3(64), 0, st, g);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(SMOE_TEAM_MAXW * 64) fit_team_kernel(FitArgs a
     const float* s_lw = lds + TT::off_lw(N, CR, nw) + grp * N;
     const bool has_lw = a.loss_w != nullptr;
 
+    SMOE_LDS_CHECK(TT::off_lw(N, CR, nw) + (has_lw ? TT::NB * N : 0), 8u);
     // ---- staging: coordinates, targets and loss weights of the four blocks (one contiguous run each) --------------------
     {
         const int nt = (int)blockDim.x;
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(SMOE_TEAM_MAXW * 64) fit_team_kernel(FitArgs a
             }
             hoist_const<D, C, K, HL, false>(R, xc);
             // pixel n = i * (16 nw) + wave * 16 + sub: the wavefronts take the 16-pixel steps of a block round robin
-            if (has_lw) pixel_loop_train<D, C, K, true, HL, false>(R, kc, s_coords, s_tgt, s_lw, N, 16 * nw, wave * 16 + sub, acc);
+            if (has_lw) pixel_loop_train<D, C, K, true, HL, false>(R, kc, s_coords, s_tgt, s_lw, N, 16 * nw, wave * 16 + sub, acc, a.lw_is_sample != 0);
             else pixel_loop_train<D, C, K, false, HL, false>(R, kc, s_coords, s_tgt, s_lw, N, 16 * nw, wave * 16 + sub, acc);
             complete_const<D, C, K, HL, false>(R, xc, acc);
         }
@@ -417,7 +418,9 @@ hipError_t launch_fit_team(const FitArgs& a, int hoist, int nw, hipStream_t st) 
     hipError_t e = allow_lds(reinterpret_cast<const void*>(kern), shm);
     if (e != hipSuccess) return e;
     const int grid = (a.B + TT::NB - 1) / TT::NB;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), shm, st, a);
+    FitArgs aa = a;
+    aa.lds_floats = (int)(shm / sizeof(float));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), shm, st, aa);
     return hipGetLastError();
 }
 

@@ -224,8 +224,11 @@ class BlockEngine:
         return out
 
     def fit(self, target, params, state: AdamState, active, n_iters: int, loss_w=None, diverged=None,
-            loss0=None, loss_out=None, sse_out=None):
+            loss0=None, loss_out=None, sse_out=None, loss_w_is_sample=False):
+        """loss_w_is_sample: ``loss_w`` is a pixel sub-sample (N / n for the drawn pixels, 0 otherwise; smoe.py:1664-1667):
+        the pixels with weight 0 are "not fed" and do not vote in the kernel-list prune (include/smoe_hip.h: smoe_set_sampling)."""
         B = self._check_target(target, loss_w)
+        _lib.check(self.lib.smoe_set_sampling(self._h, int(bool(loss_w_is_sample))))
         self._check_params(params, B)
         self._check_params(state.m, B)
         self._check_params(state.v, B)
@@ -414,6 +417,10 @@ class SharedEngine:
         state.c.v = self._cparams(state.v)
         cp = self._cparams(params)
         _lib.check(self.lib.smoe_shared_apply(self._h, C.byref(cp), C.byref(state.c), self._stream()))
+
+    def discard_gradients(self):
+        """zero_op alone (smoe.py:1613): drop what accumulate() has gathered since the last apply()."""
+        _lib.check(self.lib.smoe_shared_discard(self._h, self._stream()))
 
     def fit(self, target, params, state: AdamState, lists, n_iters, loss_out=None, sse_out=None):
         self._check_target(target, self.num_batches)

@@ -460,7 +460,8 @@ class Smoe:
             sse = torch.empty((self.B,), dtype=torch.float32, device=eng.device)
             eng.fit(self._target, self._params, self._state, self._active, 1,
                     loss_w=self._loss_w if sub_w is None else sub_w,
-                    diverged=self._diverged, loss0=self._loss0, loss_out=loss, sse_out=sse)
+                    diverged=self._diverged, loss0=self._loss0, loss_out=loss, sse_out=sse,
+                    **({} if sub_w is None else {"loss_w_is_sample": True}))
         else:
             out = eng.forward(self._target, self._params, self._active, loss_w=self._loss_w,
                               want_recon=update_reconstruction, want_argmax=update_reconstruction,
@@ -485,8 +486,10 @@ class Smoe:
         before the first one, smoe.py:270-272).  The
         reference feeds only the drawn pixels; here they get the loss weight N / n (the others 0), which gives the same
         loss and the same gradients -- `mean` over the n drawn pixels.  Draws: exponential-race keys (the successive-
-        sampling law of numpy's `choice(replace=False, p=...)`, another random stream).  Deviation: the kernel list is
-        pruned by the influence over ALL pixels of the block (a superset of the reference's list)."""
+        sampling law of numpy's `choice(replace=False, p=...)`, another random stream).  The engine is told that the weights are
+        a sample (``loss_w_is_sample``): pixels that were not drawn do not vote in the kernel-list prune, as in the reference,
+        which never sees them.  With a loss mask on top, drawn pixels the mask zeroes do not vote either (the reference
+        feeds them with weight 0: they would)."""
         B, N = self._sampl_prob.shape
         n = max(1, int(round(N * sampling_percentage / 100.0)))
         gen = getattr(self, "_sample_gen", None)
@@ -580,7 +583,8 @@ class Smoe:
         sp = getattr(self, "_train_sampling", None)
         self._engine.fit(self._target, self._params, self._state, self._active, n,
                          loss_w=self._sample_pixels(sp) if sp is not None else self._loss_w,
-                         diverged=self._diverged, loss0=self._loss0)
+                         diverged=self._diverged, loss0=self._loss0,
+                         **({} if sp is None else {"loss_w_is_sample": True}))
 
     def _readmit_kernels(self):
         self._engine.update_kernel_list(self._params, self._active)

@@ -88,11 +88,12 @@ class OracleEngine:
                 "recon": None if r["recon"] is None else torch.from_numpy(r["recon"]), "argmax": None, "gate_w": None}
 
     def fit(self, target, params, state, active, n_iters, loss_w=None, diverged=None, loss0=None, loss_out=None,
-            sse_out=None):
+            sse_out=None, loss_w_is_sample=False):
         act = active.numpy().view(np.uint32)
         state.beta_pow[:] = [state.c.beta1_power, state.c.beta2_power]      # restore() writes the c fields
-        if self.numpy_only:
-            return self._fit_numpy(target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out)
+        if self.numpy_only or loss_w_is_sample:
+            return self._fit_numpy(target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out,
+                                   loss_w=None if loss_w is None else loss_w.numpy(), sample=loss_w_is_sample)
         r = co.fit(self.ocfg, self.coords, target.numpy(), self._np(params), self._np(state.m), self._np(state.v), act,
                    n_iters, state.beta_pow, None if loss_w is None else loss_w.numpy(),
                    None if diverged is None else diverged.numpy().view(np.uint32),
@@ -104,7 +105,7 @@ class OracleEngine:
         if sse_out is not None:
             sse_out.copy_(torch.from_numpy(r["sse"]))
 
-    def _fit_numpy(self, target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out):
+    def _fit_numpy(self, target, params, state, act, n_iters, diverged, loss0, loss_out, sse_out, loss_w=None, sample=False):
         """The iteration body of oracle.fit (pass -> prune -> Adam -> divergence test) on the numpy oracle."""
         K = self.cfg.kernels
         shifts = np.arange(K, dtype=np.uint32)[None, :]
@@ -116,7 +117,8 @@ class OracleEngine:
         f = None
         for _ in range(n_iters):
             mask = ((act[:, None] >> shifts) & 1).astype(bool)
-            f = o.forward(p, tgt, self.coords.T, mask, self.ocfg, None, np.float32, want_grads=True)
+            f = o.forward(p, tgt, self.coords.T, mask, self.ocfg, None if self.ocfg.ssim_opt else loss_w, np.float32, want_grads=True,
+                          fed=(loss_w > 0) if (sample and loss_w is not None) else None)
             new = np.where(stopped[:, None], mask, f["active_new"])
             act[:] = (new.astype(np.uint32) << shifts).sum(axis=1).astype(np.uint32)
             p = o.adam_step(p, f["grads"], st, self.ocfg, np.float32, frozen=stopped)

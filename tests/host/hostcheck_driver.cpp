@@ -130,6 +130,9 @@ static void drive_handle(const smoe_config& c, bool expect_variant) {
     EXPECT(smoe_reduce_scalars(h, 3, dummy, dummy, udummy, nullptr, nullptr) == SMOE_ERR_INVALID);
     EXPECT(smoe_reduce_scalars(h, 3, dummy, dummy, udummy, ddummy, nullptr) == SMOE_OK);
     EXPECT(smoe_set_center_grid(h, dummy) == SMOE_OK && smoe_set_center_grid(h, nullptr) == SMOE_OK);
+    EXPECT(smoe_set_sampling(h, 1) == SMOE_OK && smoe_set_sampling(nullptr, 1) == SMOE_ERR_INVALID);
+    EXPECT(smoe_fit(h, 4, dummy, dummy, &p, &st, 1, nullptr, nullptr, udummy, nullptr, nullptr, nullptr) == (expect_variant ? SMOE_OK : smoe_fit(h, 4, dummy, dummy, &p, &st, 1, nullptr, nullptr, udummy, nullptr, nullptr, nullptr)));
+    EXPECT(smoe_set_sampling(h, 0) == SMOE_OK);
     EXPECT(smoe_get_coords(h, nullptr) == SMOE_ERR_INVALID);
     EXPECT(smoe_destroy(h) == SMOE_OK);
 }
@@ -246,6 +249,8 @@ static void check_shared() {
                     EXPECT(smoe_shared_forward(hs, 0, 1, dummy, &p, nullptr, nullptr, dummy, dummy, nullptr, 1, nullptr) == SMOE_ERR_INVALID);
                     EXPECT(smoe_shared_accumulate(hs, 3, NB - 3, dummy, &p, dummy, dummy, lists, nullptr) == SMOE_OK);
                     EXPECT(smoe_shared_accumulate(hs, 3, NB, dummy, &p, dummy, dummy, lists, nullptr) == SMOE_ERR_INVALID);
+                    EXPECT(smoe_shared_discard(hs, nullptr) == SMOE_OK && smoe_shared_discard(nullptr, nullptr) == SMOE_ERR_INVALID);
+                    EXPECT(smoe_shared_accumulate(hs, 0, 2, dummy, &p, dummy, dummy, lists, nullptr) == SMOE_OK);
                     EXPECT(smoe_shared_apply(hs, &p, &st, nullptr) == SMOE_OK && st.step == 1);
                     EXPECT(smoe_shared_apply(hs, &p, nullptr, nullptr) == SMOE_ERR_INVALID);
                     EXPECT(smoe_shared_fit(hs, dummy, &p, &st, 3, dummy, dummy, lists, nullptr) == SMOE_OK && st.step == 4);

@@ -129,3 +129,38 @@ def test_refused_shapes_say_why():
         with pytest.raises(_lib.SmoeError) as e:
             _engine(kw.pop("block_shape"), kw.pop("channels"), kw.pop("kernels"), **kw)
         assert e.value.code == code and str(e.value)
+
+
+@pytest.mark.parametrize("tiling", [16, 64, 128, 816])
+def test_sub_sampled_pass_prunes_by_the_fed_pixels_only(tiling):
+    """Pixel sub-sampling (smoe.py:1664-1667): the reference feeds only the drawn pixels, so a kernel stays on the list iff it
+    has influence on a DRAWN pixel (smoe.py:829,1763-1766).  The engine is told that its loss weights are a sample
+    (smoe_set_sampling): weight-0 pixels do not vote.  A kernel is confined to a corner of the block; the sample avoids that
+    corner: the sampled pass drops the kernel, the same weights as a plain loss mask keep it."""
+    shape, C, kpd = (16, 16), 1, [2, 2]
+    B = 9
+    cfg, p, coords, tgt, K = _setup(shape, C, kpd, False, B, 77, perturb=False)
+    p["A_diagonal"][:, 0] *= 6.0                       # kernel 0: narrow, around its centre (0.25, 0.25)
+    fed = np.ones((B, 256), bool).reshape(B, 16, 16)
+    fed[:, :9, :9] = False                            # nothing drawn in the corner that kernel 0 reaches
+    fed = fed.reshape(B, 256)
+    n = fed.sum(axis=1)[:, None]
+    lw = np.where(fed, 256.0 / n, 0.0).astype(np.float32)
+    active = np.ones((B, K), bool)
+    ref_s = o.forward(p, tgt, coords, active, cfg, lw, np.float32, want_grads=True, fed=fed)
+    ref_m = o.forward(p, tgt, coords, active, cfg, lw, np.float32, want_grads=True)
+    assert not ref_s["active_new"][:, 0].any() and ref_m["active_new"][:, 0].all()      # the scenario is what it claims
+    for sample, ref in ((True, ref_s), (False, ref_m)):
+        eng = _engine(shape, C, K)
+        eng.set_tiling(tiling)
+        dp = _to_dev(p)
+        st = eng.new_adam_state(dp)
+        act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
+        eng.fit(_planar(tgt), dp, st, act, 1, loss_w=torch.from_numpy(lw).cuda(), loss_w_is_sample=sample)
+        torch.cuda.synchronize()
+        got = _bits_to_mask(act.cpu().numpy().view(np.uint32), K)
+        assert np.array_equal(got, ref["active_new"]), (sample, tiling)
+        # the gradients are those of the weighted pass either way (weight 0 = no contribution)
+        g = st.m["nu_e"].cpu().numpy() / 0.1
+        assert np.abs(g - ref["grads"]["nu_e"]).max() < 3e-5 * np.abs(ref["grads"]["nu_e"]).max()
+        eng.close()
