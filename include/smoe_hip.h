@@ -199,7 +199,8 @@ int smoe_set_center_grid(smoe_handle h, const float* grid);
  * wavefronts of a workgroup in smoe_fit (other graphs and the evaluation run the plain 64-lane kernel).  216 / 416 / 816 =
  * the team tiling of smoe_fit with 2 / 4 / 8 wavefronts per workgroup: four blocks per workgroup on the 16-lane layout, the
  * wavefronts split the pixel rows (csrc/smoe_team.hip.h; the automatic choice for small batches of the plain margin-loss
- * graph; other graphs and the evaluation choose as with 0).  Tuning / test hook. */
+ * graph; other graphs and the evaluation choose as with 0).  264 = the duo tiling of smoe_fit: one block on two symmetric
+ * wavefronts with a single joint reduction and the slot owners' state in registers (csrc/smoe_duo.hip.h).  Tuning / test hook. */
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block);
 
 /* Partition invariance.  The reference walks ALL blocks of an image in one host loop (smoe.py:1643-1702): a block's

@@ -8,8 +8,9 @@ from steered_mixture_of_experts_amd import blocks as blk
 from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig
 
 PH = ["load+derive+hoist", "pixel loop+complete", "finish_partials", "reduce", "pair hand-off", "owner post", "adam", "write+refresh"]
+PH_DUO = ["load+derive+hoist", "pixel loop+complete", "partial writes", "barrier A", "row sums+publish", "barrier B", "gradient+adam+write", "barrier C"]
 shape, C, kpd, K = (16, 16), 1, [2, 2], 4
-for B, tiling in [(1024, 128), (1024, 64), (2048, 64), (4096, 32), (4096, 16), (65536, 16)]:
+for B, tiling in [(1024, 264), (1024, 128), (1024, 64), (2048, 64), (4096, 32), (4096, 16), (65536, 16)]:
     b = blk.synthetic_blocks(B, shape, C, 20260002)
     T = torch.from_numpy(blk.to_planar(b)).cuda()
     eng = BlockEngine(EngineConfig(block_shape=shape, channels=C, kernels=K, quantize_pis=True))
@@ -28,5 +29,6 @@ for B, tiling in [(1024, 128), (1024, 64), (2048, 64), (4096, 32), (4096, 16), (
     print(f"B={B} tiling={tiling} {eng.fit_variant(B)}: {e0.elapsed_time(e1) * 1e3 / n:.2f} us per iteration (whole launch)")
     for w in range(4):
         if c[w].sum() > 0:
-            print(f"  wave {w}: total {c[w].sum():8.0f} clk/iter  " + "  ".join(f"{PH[i]} {c[w][i]:.0f}" for i in range(8)))
+            names = PH_DUO if tiling == 264 else PH
+            print(f"  wave {w}: total {c[w].sum():8.0f} clk/iter  " + "  ".join(f"{names[i]} {c[w][i]:.0f}" for i in range(8)))
     eng.close()

@@ -37,7 +37,12 @@ def run_pass(out, name, counters, bench_args, steps):
     with open(os.path.join(out, f"{name}_s{steps}.log"), "w") as log:
         rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=600).returncode
     line = [l for l in open(os.path.join(out, f"{name}_s{steps}.log")) if l.startswith("{") and '"metric"' in l]
-    cfg = json.loads(line[-1])["config"] if line else {}
+    # a failed pass must not reach the committed profile files: stop here, nothing is written
+    if rc != 0:
+        sys.exit(f"pmc_collect: pass {name} (steps {steps}) failed with rc {rc}: see {out}/{name}_s{steps}.log")
+    if not line:
+        sys.exit(f"pmc_collect: pass {name} (steps {steps}) printed no bench line: see {out}/{name}_s{steps}.log")
+    cfg = json.loads(line[-1])["config"]
     agg = collections.defaultdict(float)
     cnt = collections.Counter()
     kname = None
@@ -48,6 +53,9 @@ def run_pass(out, name, counters, bench_args, steps):
             kname = r["Kernel_Name"]
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[r["Counter_Name"]] += 1
+    missing = [c for c in counters if cnt[c] == 0]
+    if missing:
+        sys.exit(f"pmc_collect: pass {name} (steps {steps}): no fit_kernel dispatch carries {missing}")
     per = {c: agg[c] / cnt[c] for c in agg}
     print(f"{name} steps={steps} rc={rc} dispatches={dict(cnt)}", flush=True)
     return per, cfg, kname
@@ -69,8 +77,10 @@ def main():
     for name in ("p3", "p4"):
         per, _, _ = run_pass(out, name, PASSES[name], bench_args, 20)
         t20.update(per)
-    variant = cfg.get("kernel_variant", "?")
+    variant = cfg.get("kernel_variant")
     B = cfg.get("blocks_rank0", 0)
+    if not variant or not B:
+        sys.exit("pmc_collect: the bench line carries no kernel_variant / blocks_rank0: nothing written")
     N = 1
     for s in cfg.get("block_shape", []):
         N *= s

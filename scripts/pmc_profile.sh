@@ -3,7 +3,8 @@
 # usage: scripts/pmc_profile.sh <outdir> [bench args...]
 set -u
 OUT=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root: the GPU box exports it; elsewhere derived from this file
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 mkdir -p "$OUT"
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 100 --warmup 0 --clock-warm-iters 0 --no-cpu-baseline --no-extras $BENCH_ARGS > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 export BENCH_ARGS="${BENCH_ARGS:-}"

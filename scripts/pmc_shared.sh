@@ -2,7 +2,8 @@
 # PMC passes for the shared-kernel pass (each pass its own rocprofv3 run).  usage: scripts/pmc_shared.sh <outdir> [bench_shared args]
 set -u
 OUT=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root: the GPU box exports it; elsewhere derived from this file
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 mkdir -p "$OUT"
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 scripts/bench_shared.py --cpu-iters 0 --steps 20 $ARGS > "$OUT/$name.log" 2>&1; echo "$name rc=$?"; }
 export ARGS="${ARGS:---image 2048 2048 --kernels-per-dim 48 48}"

@@ -1,7 +1,8 @@
 #!/bin/bash
 # kernel trace of the evaluation pass: scripts/prof_forward.sh <outdir>
 OUT=$1
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root: the GPU box exports it; elsewhere derived from this file
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 mkdir -p "$OUT"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fwd" -- python3 scripts/forward_timing.py > "$OUT/fwd.log" 2>&1
 echo rc=$?

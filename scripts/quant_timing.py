@@ -1,4 +1,4 @@
-import sys,time; sys.path.insert(0,'/root/repo')
+import sys,time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from steered_mixture_of_experts_amd import blocks as blk
 from steered_mixture_of_experts_amd.engine import BlockEngine, EngineConfig

@@ -743,7 +743,9 @@ __device__ __forceinline__ float lds_f32(const float* __restrict__ lds, uint32_t
 __device__ __forceinline__ float eval_slot_desc(const float* __restrict__ lds, const SlotDesc& d, float tot) {
     const float t1 = lds_f32(lds, d.T1), t2 = lds_f32(lds, d.T2), t3 = lds_f32(lds, d.T3), tr = lds_f32(lds, d.TR);
     const float p1 = lds_f32(lds, d.P1), p2 = lds_f32(lds, d.P2), p3 = lds_f32(lds, d.P3), pr = lds_f32(lds, d.PR);
-    const bool act = (lds_f32(lds, d.FLAG) != 0.0f) && (lds_f32(lds, d.PIV) > 0.0f);          // smoe.py:480,738
+    // (both operands loaded before the test: a short-circuit `&&` made the prior a dependent LDS read behind a branch)
+    const float flag = lds_f32(lds, d.FLAG), piv = lds_f32(lds, d.PIV);
+    const bool act = (flag != 0.0f) & (piv > 0.0f);                                             // smoe.py:480,738
     float g = d.c_self * tot;
     g = fmaf(p1, t1, g);
     g = fmaf(p2, t2, g);
@@ -2551,7 +2553,8 @@ int fit_occupancy(int N, bool has_lw, int hoist, bool pair) {
       &launch_fit_ssim<D, C, K, G, W>, &launch_fwd_ssim<D, C, K, G, W>, &lds_bytes_ssim<D, C, K, G, W>, \
       &launch_readmit_quant<D, C, K, G, W>, &launch_fit_quant<D, C, K, G, W>, &launch_fwd_quant<D, C, K, G, W>, \
       &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W>, \
-      team_fit_ptr<D, C, K, G, W>(), team_lds_ptr<D, C, K, G, W>(), team_occ_ptr<D, C, K, G, W>() }
+      team_fit_ptr<D, C, K, G, W>(), team_lds_ptr<D, C, K, G, W>(), team_occ_ptr<D, C, K, G, W>(), \
+      duo_fit_ptr<D, C, K, G>(), duo_lds_ptr<D, C, K, G>(), duo_occ_ptr<D, C, K, G>() }
 
 // Reduced instantiation for the (dim, channels, kernels) triples outside the BASELINE shapes: the margin loss with and
 // without train_inverse_cov (quantize_pis included: it lives in the default kernels); ssim_opt and quantization_mode
@@ -2560,7 +2563,8 @@ int fit_occupancy(int N, bool has_lw, int hoist, bool pair) {
     { D, C, K, G, W, "fit_d" SMOE_STR(D) "c" SMOE_STR(C) "k" SMOE_STR(K) "_g" SMOE_STR(G) "w" SMOE_STR(W), &launch_fit<D, C, K, G, W>, &launch_fwd<D, C, K, G, W>, &lds_bytes<D, C, K, G, W>, &fit_occupancy<D, C, K, G, W>, \
       nullptr, nullptr, nullptr, &launch_readmit_quant<D, C, K, G, W>, nullptr, nullptr, \
       &launch_fit_ic<D, C, K, G, W>, &launch_fwd_ic<D, C, K, G, W>, \
-      team_fit_ptr<D, C, K, G, W>(), team_lds_ptr<D, C, K, G, W>(), team_occ_ptr<D, C, K, G, W>() }
+      team_fit_ptr<D, C, K, G, W>(), team_lds_ptr<D, C, K, G, W>(), team_occ_ptr<D, C, K, G, W>(), \
+      duo_fit_ptr<D, C, K, G>(), duo_lds_ptr<D, C, K, G>(), duo_occ_ptr<D, C, K, G>() }
 
 }  // namespace smoe
 #endif

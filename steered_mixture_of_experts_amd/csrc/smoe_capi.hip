@@ -27,6 +27,7 @@ struct smoe_context {
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     long long total_blocks;   // smoe_set_total_blocks: block count of the whole job the calls are shards of (0: each call's own)
     int force_team;      // 0: by batch size, 2 / 4 / 8: team tiling with that many wavefronts per workgroup, -1: never
+    int force_duo;       // 0: by batch size, 1: duo tiling (smoe_set_tiling 264), -1: never
     int lw_is_sample;    // smoe_set_sampling: the loss_w of smoe_fit is a pixel sub-sample
     int simds;           // SIMDs of the device (4 per CU; 1 024 on MI355X): the batch-size thresholds of the tiling rules scale with it
     std::string variant_name;   // what smoe_fit_variant last returned (the team names are composed)
@@ -282,6 +283,35 @@ int team_waves(const smoe_context* h, int num_blocks, bool has_lw, const smoe::V
     return nw;
 }
 
+// Duo tiling (smoe_duo.hip.h): one block on two symmetric wavefronts, a single joint reduction, owner state in registers.
+// Returns the 64-lane variant that carries it, or null = run the regular kernels.  Same graphs as the two-wavefront form of
+// fit_kernel (wants_pair), triples with at most 128 slots.
+// Automatic up to one block per SIMD and for blocks of at most 512 pixels (profiles/r03/bench_team.txt: 1 024 blocks of 16x16
+// 92 -> 100+ Gpx-it/s against the two-wavefront form of fit_kernel, RGB 63 -> 70; 2 048 blocks: 104 vs 162 for one wavefront per
+// block -- four wavefronts per SIMD no longer pay; 1 024-pixel video blocks: 78 vs 120, their two trailing axes are hoisted in
+// fit_kernel and the pixel loop is most of their iteration).
+#ifndef SMOE_DUO_MAX_BLOCKS
+#define SMOE_DUO_MAX_BLOCKS 1024        // per 1 024 SIMDs
+#endif
+#ifndef SMOE_DUO_MAX_PIXELS
+#define SMOE_DUO_MAX_PIXELS 512
+#endif
+const smoe::Variant* duo_variant(const smoe_context* h, int num_blocks, bool has_lw) {
+    if (h->force_duo < 0 || (h->force_g && h->force_duo == 0) || h->force_team > 0) return nullptr;
+    if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov || h->kc.radial) return nullptr;
+    if (h->force_duo == 0 && (h->force_pair > 0 || h->N > SMOE_DUO_MAX_PIXELS ||
+                              choice_blocks(h, num_blocks) > (long)SMOE_DUO_MAX_BLOCKS * h->simds / 1024)) return nullptr;
+    int n = 0;
+    const smoe::Variant* v = smoe::variants(&n);
+    for (int i = 0; i < n; ++i) {
+        if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels || v[i].G != 64 || !v[i].fit_duo) continue;
+        const size_t b = v[i].duo_lds_bytes(h->N, has_lw, hoist_level(h, &v[i]));
+        if (b == (size_t)-1 || b > 160u * 1024u) return nullptr;
+        return &v[i];
+    }
+    return nullptr;
+}
+
 const smoe::Variant* find_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
@@ -390,6 +420,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
     h->force_g = 0;
     h->force_pair = 0;
     h->force_team = 0;
+    h->force_duo = 0;
     h->lw_is_sample = 0;
     h->simds = 1024;
 #if !SMOE_HOST_TEST
@@ -537,15 +568,18 @@ int smoe_set_center_grid(smoe_handle h, const float* grid) {
 int smoe_set_tiling(smoe_handle h, int32_t lanes_per_block) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_set_tiling: null handle");
     const bool team = lanes_per_block == 216 || lanes_per_block == 416 || lanes_per_block == 816;
-    if (!team && lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64 && lanes_per_block != 128)
-        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32, 64, 128, 216, 416 or 816");
+    const bool duo = lanes_per_block == 264;
+    if (!team && !duo && lanes_per_block != 0 && lanes_per_block != 16 && lanes_per_block != 32 && lanes_per_block != 64 && lanes_per_block != 128)
+        return fail(SMOE_ERR_INVALID, "smoe_set_tiling: lanes_per_block must be 0, 16, 32, 64, 128, 216, 264, 416 or 816");
     // 128 = the 64-lane kernels with one block on both wavefronts of a workgroup (margin loss, quantization_mode 0 / 1,
     // train_inverse_cov off; other graphs run the plain 64-lane kernel)
     // 216 / 416 / 816 = team tiling with 2 / 4 / 8 wavefronts per workgroup in smoe_fit (the graphs it covers; others and
     // the evaluation choose as with 0)
-    h->force_g = (lanes_per_block == 128) ? 64 : (team ? 0 : lanes_per_block);
-    h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0 || team) ? 0 : -1);
+    // 264 = duo tiling of smoe_fit (one block on two symmetric wavefronts, csrc/smoe_duo.hip.h)
+    h->force_g = (lanes_per_block == 128) ? 64 : ((team || duo) ? 0 : lanes_per_block);
+    h->force_pair = (lanes_per_block == 128) ? 1 : ((lanes_per_block == 0 || team || duo) ? 0 : -1);
     h->force_team = team ? lanes_per_block / 100 : ((lanes_per_block == 0) ? 0 : -1);
+    h->force_duo = duo ? 1 : ((lanes_per_block == 0) ? 0 : -1);
     return SMOE_OK;
 }
 
@@ -564,6 +598,13 @@ int smoe_set_total_blocks(smoe_handle h, int64_t total_blocks) {
 
 const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks) {
     if (!h) return "";
+    if (const smoe::Variant* vd = duo_variant(h, num_blocks, false)) {
+        h->variant_name = std::string(vd->name);
+        const size_t g = h->variant_name.find("_g64");
+        if (g != std::string::npos) h->variant_name.resize(g);
+        h->variant_name += "_duo64w2";
+        return h->variant_name.c_str();
+    }
     const smoe::Variant* v16 = nullptr;
     const int nw = team_waves(h, num_blocks, false, &v16);
     if (nw > 0) {
@@ -582,6 +623,7 @@ int smoe_fit_occupancy(smoe_handle h, int32_t num_blocks) {
     const smoe::Variant* v = find_variant(h, num_blocks, false);
     if (!v) return fail(SMOE_ERR_UNSUPPORTED, "smoe_fit_occupancy: no variant");
     if (hipSetDevice(h->cfg.device) != hipSuccess) return fail(SMOE_ERR_HIP, "hipSetDevice");
+    if (const smoe::Variant* vd = duo_variant(h, num_blocks, false)) return vd->duo_waves_per_cu(h->N, false, hoist_level(h, vd));
     const smoe::Variant* v16 = nullptr;
     const int nw = team_waves(h, num_blocks, false, &v16);
     if (nw > 0) return v16->team_waves_per_cu(h->N, false, nw);
@@ -649,7 +691,9 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     a.lw_is_sample = (h->lw_is_sample && loss_w != nullptr && !c.ssim_opt) ? 1 : 0;
     const smoe::Variant* v16 = nullptr;
     const int team = team_waves(h, num_blocks, loss_w != nullptr, &v16);
-    if (team > 0) HIP_TRY(v16->fit_team(a, hoist_level(h, v16), team, (hipStream_t)stream), "smoe_fit (team) launch");
+    const smoe::Variant* vduo = duo_variant(h, num_blocks, loss_w != nullptr);
+    if (vduo) HIP_TRY(vduo->fit_duo(a, hoist_level(h, vduo), (hipStream_t)stream), "smoe_fit (duo) launch");
+    else if (team > 0) HIP_TRY(v16->fit_team(a, hoist_level(h, v16), team, (hipStream_t)stream), "smoe_fit (team) launch");
     else if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");
     else if (h->kc.qmode) HIP_TRY(v->fit_quant(a, hoist, (hipStream_t)stream), "smoe_fit (quantised) launch");
     else if (h->kc.inverse_cov) HIP_TRY(v->fit_ic(a, hoist, (hipStream_t)stream), "smoe_fit (inverse covariance) launch");

@@ -132,6 +132,10 @@ struct Variant {
     hipError_t (*fit_team)(const FitArgs&, int hoist_level, int nw, hipStream_t);
     size_t (*team_lds_bytes)(int N, bool has_lw, int nw);
     int (*team_waves_per_cu)(int N, bool has_lw, int nw);
+    // duo tiling (smoe_duo.hip.h; entries of the 64-lane variants only): one block on two symmetric wavefronts
+    hipError_t (*fit_duo)(const FitArgs&, int hoist_level, hipStream_t);
+    size_t (*duo_lds_bytes)(int N, bool has_lw, int hoist_level);      // (size_t)-1: the triple has too many slots
+    int (*duo_waves_per_cu)(int N, bool has_lw, int hoist_level);
 };
 
 // ---- shared-kernel image mode (smoe_shared.hip) ----------------------------------------------

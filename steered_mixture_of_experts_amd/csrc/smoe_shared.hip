@@ -608,12 +608,28 @@ __device__ __forceinline__ void gather_kernel_sums(const SharedGatherArgs& g, in
     cnt = 0.0;
     const int w = k >> 5;
     const uint32_t bit = 1u << (k & 31);
-    for (int b = lane; b < g.NB_total; b += 64) {
-        if (g.batch_epoch[b] != g.epoch || !(g.trained[(size_t)b * g.KW + w] & bit)) continue;
-        const float* row = g.part + ((size_t)b * g.K + k) * PK;
+    // four batches per trip, every load unconditional (a row that was not written this pass is valid memory whose content
+    // is dropped by the select): the loads of a trip are independent, one memory latency instead of three per batch
+    constexpr int UB = 4;
+    for (int b0 = lane; b0 < g.NB_total; b0 += 64 * UB) {
+        uint32_t ep[UB], tw[UB];
+        float row[UB][PK];
 #pragma unroll
-        for (int j = 0; j < PK; ++j) s[j] += (double)row[j];
-        cnt += 1.0;
+        for (int u = 0; u < UB; ++u) {
+            const int b = min(b0 + 64 * u, g.NB_total - 1);
+            ep[u] = g.batch_epoch[b];
+            tw[u] = g.trained[(size_t)b * g.KW + w];
+            const float* r = g.part + ((size_t)b * g.K + k) * PK;
+#pragma unroll
+            for (int j = 0; j < PK; ++j) row[u][j] = r[j];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const bool on = (b0 + 64 * u < g.NB_total) && (ep[u] == g.epoch) && ((tw[u] & bit) != 0u);
+#pragma unroll
+            for (int j = 0; j < PK; ++j) s[j] += on ? (double)row[u][j] : 0.0;
+            cnt += on ? 1.0 : 0.0;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

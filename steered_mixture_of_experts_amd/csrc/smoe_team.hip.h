@@ -81,7 +81,8 @@ __device__ __forceinline__ int team_slot_tensor(int o, int& chan) {
 __device__ __forceinline__ float team_eval_desc(const float* __restrict__ lds, const SlotDesc& d, float tot, uint32_t pb) {
     const float t1 = lds_f32(lds, d.T1), t2 = lds_f32(lds, d.T2), t3 = lds_f32(lds, d.T3), tr = lds_f32(lds, d.TR);
     const float p1 = lds_f32(lds, d.P1 + pb), p2 = lds_f32(lds, d.P2 + pb), p3 = lds_f32(lds, d.P3 + pb), pr = lds_f32(lds, d.PR + pb);
-    const bool act = (lds_f32(lds, d.FLAG + pb) != 0.0f) && (lds_f32(lds, d.PIV + pb) > 0.0f);          // smoe.py:480,738
+    const float flag = lds_f32(lds, d.FLAG + pb), piv = lds_f32(lds, d.PIV + pb);      // both loaded before the test: no dependent read
+    const bool act = (flag != 0.0f) & (piv > 0.0f);                                    // smoe.py:480,738
     float g = d.c_self * tot;
     g = fmaf(p1, t1, g);
     g = fmaf(p2, t2, g);

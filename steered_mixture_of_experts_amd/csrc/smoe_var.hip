@@ -2,6 +2,7 @@
 // smoe_variants.def with -DSMOE_D= -DSMOE_C= -DSMOE_K= -DSMOE_FULL= (csrc/Makefile).
 #include "smoe_block.hip.h"
 #include "smoe_team.hip.h"
+#include "smoe_duo.hip.h"
 
 #if !defined(SMOE_D) || !defined(SMOE_C) || !defined(SMOE_K) || !defined(SMOE_FULL)
 #error "compile with -DSMOE_D -DSMOE_C -DSMOE_K -DSMOE_FULL (see csrc/Makefile)"

@@ -81,7 +81,7 @@ static void drive_handle(const smoe_config& c, bool expect_variant) {
     smoe_params p = {dummy, dummy, dummy, dummy, dummy, dummy};
     smoe_params bad = p; bad.A_corr = nullptr;
     smoe_adam_state st; st.m = p; st.v = p; st.beta1_power = 0.9f; st.beta2_power = 0.999f; st.step = 0;
-    static const int tilings[] = {0, 16, 32, 64, 128, 216, 416, 816, 0};
+    static const int tilings[] = {0, 16, 32, 64, 128, 216, 264, 416, 816, 0};
     static const int blocks[] = {1, 3, 4, 5, 1023, 1024, 1025, 1536, 3071, 3072, 8191, 8192, 65536, 1 << 30};
     for (int t : tilings) {
         EXPECT(smoe_set_tiling(h, t) == SMOE_OK);
@@ -168,6 +168,13 @@ static void check_variant_tables() {
         EXPECT(v[i].name != nullptr && std::strlen(v[i].name) > 6);
         EXPECT(v[i].G == 16 || v[i].G == 32 || v[i].G == 64);
         EXPECT((v[i].fit_team != nullptr) == (v[i].G == 16));
+        EXPECT((v[i].fit_duo != nullptr) == (v[i].G == 64));
+        if (v[i].duo_lds_bytes)
+            for (int N : {1, 35, 256, 1024, 8192})
+                for (int hl = 0; hl < 2; ++hl) {
+                    const size_t db = v[i].duo_lds_bytes(N, true, hl);
+                    EXPECT(db == (size_t)-1 || (db > sizeof(float) * (size_t)(v[i].C * N) && db < (size_t)1 << 31 && (db & 15) == 0));
+                }
         for (int N : {1, 35, 256, 1000, 1024, 4096, 8192})
             for (int lw = 0; lw < 2; ++lw)
                 for (int hq = 0; hq < 2; ++hq) {

@@ -131,7 +131,7 @@ def test_refused_shapes_say_why():
         assert e.value.code == code and str(e.value)
 
 
-@pytest.mark.parametrize("tiling", [16, 64, 128, 816])
+@pytest.mark.parametrize("tiling", [16, 64, 128, 816, 264])
 def test_sub_sampled_pass_prunes_by_the_fed_pixels_only(tiling):
     """Pixel sub-sampling (smoe.py:1664-1667): the reference feeds only the drawn pixels, so a kernel stays on the list iff it
     has influence on a DRAWN pixel (smoe.py:829,1763-1766).  The engine is told that its loss weights are a sample

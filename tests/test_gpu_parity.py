@@ -51,8 +51,19 @@ ALL_SHAPES = [(s, 16) for s in SHAPES] + [(s, 64) for s in SHAPES] + [(s, 32) fo
 # 216 / 416 / 816 = team tiling of smoe_fit (csrc/smoe_team.hip.h): four blocks per workgroup of 2 / 4 / 8 wavefronts on the
 # 16-lane layout; block shapes whose last axis divides 16
 TEAM_OK = [s for s in SHAPES + EXTRA_SHAPES if 16 % s[0][-1] == 0]
+# 264 = duo tiling of smoe_fit (csrc/smoe_duo.hip.h): one block on two symmetric wavefronts; triples with at most 128 slots
+
+
+def _duo_rows(s):
+    """rows of the joint scratch the first wavefront sums: the slots of half the kernels + the loss + their influence counters"""
+    d, C, K = len(s[0]), s[1], int(np.prod(s[2]))
+    kh = (K + 1) // 2
+    return kh * (1 + d + d * (d + 1) // 2 + C + d * C) + 1 + kh
+
+
+DUO_OK = [s for s in SHAPES + EXTRA_SHAPES if _duo_rows(s) <= 64]
 FIT_SHAPES = ALL_SHAPES + [(s, 128) for s in SHAPES] + [(s, 128) for s in EXTRA_SHAPES[::3]] \
-    + [(s, 816) for s in TEAM_OK] + [(s, 416) for s in TEAM_OK[:6]] + [(s, 216) for s in TEAM_OK[:6]]
+    + [(s, 816) for s in TEAM_OK] + [(s, 416) for s in TEAM_OK[:6]] + [(s, 216) for s in TEAM_OK[:6]] + [(s, 264) for s in DUO_OK]
 
 
 def _ids(cases):
@@ -185,7 +196,8 @@ def test_one_step_parity(case, tiling):
     active = np.ones((B, K), dtype=bool)
     eng = _engine(shape, C, K, use_yuv=yuv)
     eng.set_tiling(tiling)
-    assert ("team16w%d" % (tiling // 100) in eng.fit_variant(B)) == (tiling > 128)
+    assert ("team16w%d" % (tiling // 100) in eng.fit_variant(B)) == (tiling in (216, 416, 816))
+    assert ("duo64w2" in eng.fit_variant(B)) == (tiling == 264)
     dp = _to_dev(p)
     act = torch.from_numpy(_mask_to_bits(active).view(np.int32)).cuda()
     T = _planar(tgt)
@@ -373,7 +385,7 @@ def test_short_trajectory_vs_sensitivity_floor():
     eng.close()
 
 
-@pytest.mark.parametrize("tiling,B", [(816, 1024), (416, 37), (216, 150)])
+@pytest.mark.parametrize("tiling,B", [(816, 1024), (416, 37), (216, 150), (264, 1024), (264, 5)])
 def test_team_tiling_follows_the_restatement_over_a_trajectory(tiling, B):
     """The team kernel (four blocks per workgroup, the wavefronts split the pixel rows; double-buffered parameters, derived
     constants published by the slot owners) over 40 iterations incl. the kernel-list pruning and a batch that does not fill
@@ -389,7 +401,7 @@ def test_team_tiling_follows_the_restatement_over_a_trajectory(tiling, B):
     for _ in range(2):
         eng = _engine(shape, C, K, lr_steer=1e-2, quantize_pis=True)
         eng.set_tiling(tiling)
-        assert "team16w%d" % (tiling // 100) in eng.fit_variant(B)
+        assert ("duo64w2" if tiling == 264 else "team16w%d" % (tiling // 100)) in eng.fit_variant(B)
         dp = _to_dev(p)
         state = eng.new_adam_state(dp)
         act = torch.full((B,), (1 << K) - 1, dtype=torch.int32, device="cuda")
@@ -438,7 +450,7 @@ def test_gentle_lr_trajectory_tight():
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [0, 416, 816])
+@pytest.mark.parametrize("tiling", [0, 416, 816, 264])
 def test_frozen_blocks_and_divergence_flag(tiling):
     shape, C, kpd = (16, 16), 1, [2, 2]
     B = 8
@@ -519,7 +531,7 @@ def test_error_paths():
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [16, 64, 128, 216, 816])
+@pytest.mark.parametrize("tiling", [16, 64, 128, 216, 816, 264])
 def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     """The fit kernel's per-pixel loss-weight path (padding / loss masks, smoe.py:550,932), the l1
     regularisers (smoe.py:1027,1044) and gradient clipping (smoe.py:1152-1153) against the oracle."""
@@ -565,7 +577,7 @@ def test_fit_with_loss_weights_regularisers_and_clipping(tiling):
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [16, 64, 128, 416])
+@pytest.mark.parametrize("tiling", [16, 64, 128, 416, 264])
 def test_only_y_gamma(tiling):
     """gamma_mask (smoe.py:725-729): slopes act and train only for channel 0."""
     shape, C, kpd = (16, 16), 3, [2, 2]
@@ -597,7 +609,7 @@ def test_only_y_gamma(tiling):
     eng.close()
 
 
-@pytest.mark.parametrize("tiling", [0, 816])
+@pytest.mark.parametrize("tiling", [0, 816, 264])
 @pytest.mark.parametrize("qpis", [False, True])
 def test_kernel_count_as_norm_l1(qpis, tiling):
     """kernel_count_as_norm_l1 (smoe.py:1022-1027): the pis l1 term is normalised by the number of kernels with

@@ -122,10 +122,10 @@ def test_bench_strong_scaling_is_bit_identical_at_one_and_two_ranks():
     assert two["config"]["kernel_variant_per_rank"][0].split()[0] == one["config"]["kernel_variant_per_rank"][0].split()[0]
     assert one["state_digest"] == two["state_digest"]
     assert one["final_psnr_db"] == two["final_psnr_db"] and one["diverged_blocks"] == two["diverged_blocks"]
-    small = ["--scaling", "strong", "--image", "512", "1024"]       # 2 048 blocks: 64 lanes; halves of 1 024: block over two wavefronts
+    small = ["--scaling", "strong", "--image", "512", "1024"]       # 2 048 blocks: 64 lanes; halves of 1 024: block over two wavefronts (duo)
     one_s = _bench(["--gpus", "1"] + small)
     two_s = _bench(["--gpus", "2", "--backend", "gloo"] + small, {"SMOE_BENCH_SHARE_GPU": "1"})
     two_l = _bench(["--gpus", "2", "--backend", "gloo", "--tiling-scope", "local"] + small, {"SMOE_BENCH_SHARE_GPU": "1"})
     assert one_s["state_digest"] == two_s["state_digest"]
-    assert two_l["config"]["kernel_variant_per_rank"][0] == two_s["config"]["kernel_variant_per_rank"][0]   # same name ...
-    assert two_l["state_digest"] != one_s["state_digest"]          # ... but the two-wavefront form sums in another order
+    assert "duo64w2" in two_l["config"]["kernel_variant_per_rank"][0] and "duo" not in two_s["config"]["kernel_variant_per_rank"][0]
+    assert two_l["state_digest"] != one_s["state_digest"]          # the two-wavefront tiling of a 1 024-block shard sums in another order
