@@ -477,10 +477,10 @@ def worker(args):
                   "value": round(v1, 1), "unit": "Mpixel-iters/s", "ms_total": round(ms1, 4), "reps": len(ms_list),
                   "contract_frac": round(v1 * 1e6 * bpi1 / 1e9 / HBM_PEAK_GBS, 4),
                   "kernel_variant": eng1.fit_variant(Bs),
-                  "note": "1024 blocks = one wavefront per SIMD: each block runs on BOTH wavefronts of a workgroup "
-                          "(fit_kernel PAIR, the library's choice up to 1024 blocks); a lone wavefront issues one VALU "
-                          "instruction per ~5.6 cycles, so the ~770 instructions per iteration outside the pixel loop bound "
-                          "it (DESIGN.md section 4)"}
+                  "note": "1024 blocks = one block per SIMD: each block runs on the two wavefronts of a workgroup (duo tiling, "
+                          "csrc/smoe_duo.hip.h: joint reduction, the slot owners' state in registers, published derived constants); "
+                          "the iteration is a chain of LDS hand-offs plus ~1 500 instructions per block on two wavefronts per SIMD "
+                          "(DESIGN.md section 4b, profiles/r03/phase_clocks_duo.txt)"}
         eng1.close()
 
     if rank == 0:

@@ -270,7 +270,7 @@ def test_one_step_parity(case, tiling):
 
 def test_cfg1_single_block_forward_and_200_iterations():
     """BASELINE configs[0] on the HIP path: ONE 16x16 grayscale block, K = 4, 200 Adam iterations (B = 1: one workgroup,
-    the block on both of its wavefronts, 255 idle CUs; the tail-block path of every loader).  Six different blocks, each
+    the block on both of its wavefronts (duo tiling), 255 idle CUs; the tail-block path of every loader).  Six different blocks, each
     run alone.  Evaluation pass against the restatement; the 200-iteration fit at the CLI defaults inside the restatement's
     own fp32-vs-fp64 floor; with a well-conditioned steering step (lr_mult 10) within 0.05 dB and parameter-close."""
     shape, C, kpd, K, N = (16, 16), 1, [2, 2], 4, 256
@@ -284,7 +284,7 @@ def test_cfg1_single_block_forward_and_200_iterations():
         T = _planar(tgt)
         cfg = o.OracleConfig(block_shape=shape, channels=C, kernels=K, quantize_pis=True)
         eng = _engine(shape, C, K, quantize_pis=True)
-        assert eng.fit_variant(1).endswith("_g64w2")
+        assert eng.fit_variant(1).endswith("_duo64w2")        # one block: the two-wavefront (duo) tiling
         # evaluation of the single block
         dp = _to_dev(p)
         act = torch.full((1,), 15, dtype=torch.int32, device="cuda")
