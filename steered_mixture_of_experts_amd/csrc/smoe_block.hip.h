@@ -1811,15 +1811,22 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 }
             }
         }
-        float newp[T::SPL];
-        bool bad = false;
+        // The old value and both Adam slots of every owned slot are read first, in one batch (one LDS wait for the phase instead
+        // of one per slot), the update is branch-free, and the new slots are stored together with the new parameters below.
+        float newp[T::SPL], newm[T::SPL], newv[T::SPL], pvs[T::SPL], mvs[T::SPL], vvs[T::SPL];
 #pragma unroll
         for (int s = 0; s < T::SPL; ++s) {
             const int j = T::slot_of(sub, s);
             const int jc = (j < Lt::NPAR) ? j : 0;
-            const float pv = s_par[jc];
-            const float mv = s_mv[2 * jc];
-            const float vv = s_mv[2 * jc + 1];
+            pvs[s] = s_par[jc];
+            mvs[s] = s_mv[2 * jc];
+            vvs[s] = s_mv[2 * jc + 1];
+        }
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < T::SPL; ++s) {
+            const int j = T::slot_of(sub, s);
+            const float pv = pvs[s], mv = mvs[s], vv = vvs[s];
             float gsum = gq[s];
             // fixed-range fake quant: straight-through inside the nudged range only
             if constexpr (QUANT) {
@@ -1835,13 +1842,13 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             const float p2 = pv - (m2 * alpha) * fast_rcp(__builtin_amdgcn_sqrtf(v2) + adam_eps);
             const bool upd = (j < Lt::NPAR) && (lr[s] != 0.0f) && !frozen;
             newp[s] = upd ? p2 : pv;
-            if (upd) { s_mv[2 * jc] = m2; s_mv[2 * jc + 1] = v2; }
-            if (j == Lt::S_LOSS && !frozen) {
-                const float lossv = (SSIM ? 1.0f + total[s] : total[s]) + reg_loss;     // smoe.py:1010: 1 - ssim
-                last_loss = lossv;
-                bad = (lossv != lossv) || (has_loss0 && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f));
-            }
-            if (j == Lt::S_SSE && !frozen) last_sse = total[s];
+            newm[s] = upd ? m2 : mv;
+            newv[s] = upd ? v2 : vv;
+            const float lossv = (SSIM ? 1.0f + total[s] : total[s]) + reg_loss;         // smoe.py:1010: 1 - ssim
+            const bool is_loss = (j == Lt::S_LOSS) && !frozen;
+            last_loss = is_loss ? lossv : last_loss;
+            bad = bad || (is_loss && ((lossv != lossv) || (has_loss0 && (lossv + 1.0f > (loss0 + 100.0f) * 10.0f))));
+            last_sse = ((j == Lt::S_SSE) && !frozen) ? total[s] : last_sse;
         }
         wave_lds_sync();   // every lane has consumed the old flags / params
         SMOE_CLK(6);
@@ -1850,6 +1857,8 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             const int j = T::slot_of(sub, s);
             if (j < Lt::NPAR) {
                 s_par[j] = newp[s];
+                s_mv[2 * j] = newm[s];
+                s_mv[2 * j + 1] = newv[s];
                 if constexpr (!QUANT) {
                     // quantize_pis alone (the CLI default): the owner of a prior publishes its fake-quantised value with the new
                     // prior itself (one LDS hand-off less per iteration than a separate refresh_quantised_image pass)
