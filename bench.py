@@ -388,17 +388,14 @@ def worker(args):
     times, locals_ = [], []
     t, tl = timed_once(events)
     times.append(t); locals_.append(tl)
-    reps = 1
     if t < MIN_TIMED_S and not args.no_reps:
-        reps = int(min(args.max_reps, max(3, math.ceil(MIN_TIMED_S / max(t, 1e-6)))))
-        if dist is not None:                       # the same count on every rank
-            rr = torch.tensor([reps], dtype=torch.int64, device=dev)
-            dist.broadcast(rr, 0)
-            reps = int(rr.item())
-        for _ in range(reps - 1):
+        # repeated until MIN_TIMED_S of timed work has been done (at least three times): every rank sees the same all-reduced
+        # times, so every rank takes the same decision
+        while (len(times) < 3 or sum(times) < MIN_TIMED_S) and len(times) < args.max_reps:
             restore(start)
             t, tl = timed_once(events)
             times.append(t); locals_.append(tl)
+    reps = len(times)
     t_wall = float(np.median(times))
     del start
 

@@ -516,9 +516,10 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         const float cwl = kc.cw[c] * lw;
         if (!EXTG) acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
         if (TRAIN) {
-            // sign(diff) in {-1,0,1}: |diff| is either 0 or >= 2^-30, so diff * 2^100 saturates the clamp
-            const float sg = __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -1.0f, 1.0f);
-            const float gm = EXTG ? gext[c] : (cwl + cwl) * (ad * sg);
+            // 2 cwl sign(diff): |diff| is either 0 or >= 2^-30, so diff * 2^100 saturates the clamp to +-2 cwl (loss weights are
+            // not negative); ad * (+-2 cwl) rounds like 2 cwl * (+-ad): one multiply less than sign first, weight second
+            const float c2 = cwl + cwl;
+            const float gm = EXTG ? gext[c] : ad * __builtin_amdgcn_fmed3f(diff * 1.2676506e30f, -c2, c2);
             // clip_by_value / fake-quant straight-through: gradient only where neither clamp acted
             Gc[c] = (yc == y[c]) ? gm : 0.0f;
             dot = (c == 0) ? Gc[c] * y[c] : fmaf(Gc[c], y[c], dot);   // sum_k h_k w_k == sum_c G_c y_c
@@ -529,6 +530,11 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
     // u_k = w_k (h_k - dot) with h_k = M_k (e_k.G)  ==  wt_k (e_k.G) - w_k dot ;
     // when the normaliser sits on its 1e-11 floor it is a constant and the dot term drops.
     dot = (S > 10e-12f) ? dot : 0.0f;
+    float Gx[(D - HL > 0) ? D - HL : 1][C];
+#pragma unroll
+    for (int l = 0; l < D - HL; ++l)
+#pragma unroll
+        for (int c = 0; c < C; ++c) Gx[l][c] = Gc[c] * x[l];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float eg = e[k][0] * Gc[0];
@@ -560,13 +566,14 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
                 a[Lt::O_A + tri_index(l, m)] = fmaf(x[l], uz, a[Lt::O_A + tri_index(l, m)]);
         }
         }
+        // sum wt_k G_c and sum wt_k (G_c x_l) as fused multiply-adds on the per-pixel products G_c x_l (one instruction per
+        // accumulator; the product wt_k G_c of every kernel and channel is never formed)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float wg = o.wt[k] * Gc[c];
-            a[Lt::O_NU + c] += wg;
+            a[Lt::O_NU + c] = fmaf(o.wt[k], Gc[c], a[Lt::O_NU + c]);
 #pragma unroll
             for (int l = 0; l < D - HL; ++l)
-                a[Lt::O_GA + l * C + c] = fmaf(wg, x[l], a[Lt::O_GA + l * C + c]);
+                a[Lt::O_GA + l * C + c] = fmaf(o.wt[k], Gx[l][c], a[Lt::O_GA + l * C + c]);
         }
     }
 }
