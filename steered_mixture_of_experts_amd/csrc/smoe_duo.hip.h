@@ -59,6 +59,7 @@ struct DuoTile {
     }
 };
 
+
 template <int D, int C, int K, int HL>
 __global__ void __launch_bounds__(128) fit_duo_kernel(FitArgs a) {
     using Lt = Layout<D, C, K>;
@@ -79,6 +80,9 @@ __global__ void __launch_bounds__(128) fit_duo_kernel(FitArgs a) {
     float* s_tgt = lds + DT::off_tgt(N, CR);
     float* s_lw = lds + DT::off_lw(N, CR);
     SMOE_LDS_CHECK(DT::off_lw(N, CR) + (has_lw ? N : 0), 16u);
+    // the wavefront's 64 columns of the joint scratch as an M0 base for ds_write_addtid_b32 (0: scratch beyond the first 64 KB)
+    const uint32_t scr_end = lds_address(s_scr) + (uint32_t)(Lt::NSLOT * DT::ROWW * sizeof(float));
+    const uint32_t scr_m0 = (scr_end <= 65536u) ? __builtin_amdgcn_readfirstlane(lds_address(s_scr) + (uint32_t)(wave * 64 * sizeof(float))) : 0u;
 
     // ---- staging ------------------------------------------------------------------------------------------------------------
     for (int i = threadIdx.x; i < CR * N; i += 128) s_coords[i] = a.coords[i];
@@ -255,8 +259,12 @@ __global__ void __launch_bounds__(128) fit_duo_kernel(FitArgs a) {
                 SMOE_CLK(1);
             }
             // ---- joint scratch: row j holds the 128 partial sums of slot j ---------------------------------------------------------
+            if (scr_m0 != 0u) {
+                addtid_store_rows<DT::ROWW * (int)sizeof(float), Lt::NSLOT>(acc, scr_m0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < Lt::NSLOT; ++j) s_scr[j * DT::ROWW + threadIdx.x] = acc[j];
+                for (int j = 0; j < Lt::NSLOT; ++j) s_scr[j * DT::ROWW + threadIdx.x] = acc[j];
+            }
         }
         SMOE_CLK(2);
         __syncthreads();
