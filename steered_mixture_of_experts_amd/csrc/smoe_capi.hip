@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -773,6 +774,10 @@ struct smoe_shared_context {
     uint32_t* d_trained;  // [NB][KW]
     uint32_t* d_batch_epoch;  // [NB]
     uint32_t epoch;       // current pass (bumped by smoe_shared_apply)
+    uint32_t* d_bar;      // grid barrier of the one-launch fit (shared_fit_kernel): SharedFitArgs::bar
+    size_t bar_words;
+    bool fit_pending;     // a one-launch fit has been issued and its abort word not looked at yet
+    int num_cus;          // compute units of the device (co-residency test of the one-launch fit)
     float* d_ssim_T;      // ssim_opt: banded tap tables of the batch shape
     float* d_qrng;        // SharedRangesArgs records (mode-3 ranges, count of qpis > 0)
     bool need_ranges;     // quantization_mode 3 or kernel_count_as_norm_l1
@@ -915,6 +920,13 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
     const size_t nacc = (size_t)cfg->kernels * h->PK + cfg->kernels;
     h->d_axes = nullptr; h->d_probes = nullptr; h->d_racc = nullptr; h->d_ssim_T = nullptr; h->d_qrng = nullptr; h->loss_w = nullptr; h->mus_grid = nullptr;
     h->d_part = nullptr; h->d_trained = nullptr; h->d_batch_epoch = nullptr; h->epoch = 1u;
+    h->d_bar = nullptr; h->num_cus = 0; h->fit_pending = false;
+#if !SMOE_HOST_TEST
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
+#endif
     h->need_ranges = cfg->quantization_mode == 3 || cfg->kernel_count_as_norm_l1 != 0;
     if (cfg->ssim_opt) {
         const size_t need = smoe::shared_lds_bytes(cfg->dim, cfg->channels, cfg->kernels, h->KW) +
@@ -941,6 +953,9 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
             if (e == hipSuccess) e = dev_zero(h->d_batch_epoch, sizeof(uint32_t) * (size_t)NB);
         }
     }
+    h->bar_words = (size_t)16 + (((size_t)NB + 3) & ~(size_t)3);
+    if (e == hipSuccess) e = dev_malloc(&h->d_bar, sizeof(uint32_t) * h->bar_words);
+    if (e == hipSuccess) e = dev_zero(h->d_bar, sizeof(uint32_t) * h->bar_words);
     if (e == hipSuccess) e = dev_malloc(&h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess) e = dev_zero(h->d_qrng, sizeof(float) * smoe::SHARED_QRNG_FLOATS);
     if (e == hipSuccess && cfg->ssim_opt) {
@@ -961,6 +976,7 @@ int smoe_shared_create(smoe_shared_handle* out, const smoe_shared_config* cfg) {
         if (h->d_part) dev_free(h->d_part);
         if (h->d_trained) dev_free(h->d_trained);
         if (h->d_batch_epoch) dev_free(h->d_batch_epoch);
+        if (h->d_bar) dev_free(h->d_bar);
         delete h;
         return fail_hip(e, "smoe_shared_create: workspace");
     }
@@ -1010,6 +1026,7 @@ int smoe_shared_destroy(smoe_shared_handle h) {
     if (h->d_part) dev_free(h->d_part);
     if (h->d_trained) dev_free(h->d_trained);
     if (h->d_batch_epoch) dev_free(h->d_batch_epoch);
+    if (h->d_bar) dev_free(h->d_bar);
     delete h;
     return SMOE_OK;
 }
@@ -1036,6 +1053,28 @@ int smoe_shared_grad_buffer(smoe_shared_handle h, double** dev_ptr, int64_t* cou
     return SMOE_OK;
 }
 
+// opt-in (SMOE_SHARED_ONE_LAUNCH=1): measured SLOWER than the two launches per iteration on MI355X (32.4 vs 27.7 us per
+// iteration, 512x512 / 144 kernels; profiles/r03/shared_one_launch.txt) -- what crosses workgroups inside a launch has to bypass
+// the per-XCD L2 caches, ~2 us per dependent access, nine of them per iteration; two kernel boundaries are cheaper
+static bool shared_one_launch_enabled() {
+    const char* v = std::getenv("SMOE_SHARED_ONE_LAUNCH");
+    return v && v[0] == '1';
+}
+
+// a one-launch fit whose grid barrier timed out raised the abort word and left early: reported by the next call of the handle
+static int shared_check_abort(smoe_shared_handle h, const char* who) {
+    if (!h->fit_pending) return SMOE_OK;
+    h->fit_pending = false;
+#if !SMOE_HOST_TEST
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return SMOE_OK;
+    hipError_t e = hipMemcpy(w, h->d_bar, sizeof(w), hipMemcpyDeviceToHost);     // synchronises with the fit
+    if (e != hipSuccess) return fail_hip(e, who);
+    if (w[2] != 0u) return fail(SMOE_ERR_HIP, std::string(who) + ": the previous smoe_shared_fit launch aborted (grid barrier timed out); its results are invalid");
+#endif
+    return SMOE_OK;
+}
+
 int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_batches, const float* target,
                         const smoe_params* p, float* recon, int32_t* argmax, float* loss, float* sse,
                         uint32_t* lists, int32_t update_lists, void* stream) {
@@ -1044,6 +1083,8 @@ int smoe_shared_forward(smoe_shared_handle h, int32_t first_batch, int32_t num_b
     if (rc) return rc;
     if (num_batches == 0) return SMOE_OK;
     if (!target || !params_ok(p) || !lists) return fail(SMOE_ERR_INVALID, "smoe_shared_forward: target, params and lists are required");
+    rc = shared_check_abort(h, "smoe_shared_forward");
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
     smoe::SharedArgs a;
     fill_shared_args(h, a);
@@ -1078,12 +1119,8 @@ static int shared_accumulate_impl(smoe_shared_handle h, int32_t first_batch, int
     return SMOE_OK;
 }
 
-static int shared_apply_impl(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream, bool gather) {
-    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: null handle");
-    if (!params_ok(p) || !s || !params_ok(&s->m) || !params_ok(&s->v)) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: params and adam state are required");
-    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+static void fill_adam_args(const smoe_shared_context* h, const smoe_params* p, const smoe_adam_state* s, smoe::SharedAdamArgs& a) {
     const smoe_shared_config& c = h->cfg;
-    smoe::SharedAdamArgs a;
     a.p = *p; a.m = s->m; a.v = s->v;
     a.racc = h->d_racc; a.nact = h->d_racc + (size_t)c.kernels * h->PK; a.K = c.kernels;
     a.b1p = s->beta1_power; a.b2p = s->beta2_power; a.beta1 = c.beta1; a.beta2 = c.beta2; a.eps = c.adam_eps;
@@ -1096,6 +1133,15 @@ static int shared_apply_impl(smoe_shared_handle h, smoe_params* p, smoe_adam_sta
     a.qrng = h->d_qrng;
     a.mus_grid = h->mus_grid;
     fill_gather_args(h, a.gather);
+}
+
+static int shared_apply_impl(smoe_shared_handle h, smoe_params* p, smoe_adam_state* s, void* stream, bool gather) {
+    if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: null handle");
+    if (!params_ok(p) || !s || !params_ok(&s->m) || !params_ok(&s->v)) return fail(SMOE_ERR_INVALID, "smoe_shared_apply: params and adam state are required");
+    HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+    const smoe_shared_config& c = h->cfg;
+    smoe::SharedAdamArgs a;
+    fill_adam_args(h, p, s, a);
     const bool fused = gather && h->d_part != nullptr && h->kc.qmode != 3;      // the mode-3 step is ONE workgroup over all kernels
     if (gather && h->d_part != nullptr && !fused)
         HIP_TRY(smoe::launch_shared_gather(a.gather, (hipStream_t)stream), "smoe_shared_apply gather");
@@ -1134,6 +1180,49 @@ int smoe_shared_fit(smoe_shared_handle h, const float* target, smoe_params* p, s
                     float* loss_last, float* sse_last, uint32_t* lists, void* stream) {
     if (!h) return fail(SMOE_ERR_INVALID, "smoe_shared_fit: null handle");
     if (n_iters < 0) return fail(SMOE_ERR_INVALID, "smoe_shared_fit: negative n_iters");
+    if (n_iters == 0) return SMOE_OK;
+    {
+        int rc = shared_check_abort(h, "smoe_shared_fit");
+        if (rc) return rc;
+    }
+    // SMOE_SHARED_ONE_LAUNCH=1: ONE launch for all n_iters iterations when every batch can keep a workgroup on the device
+    // (shared_fit_kernel: the same pass / gather / step code between grid barriers, bit-identical to the loop below)
+    if (h->d_part != nullptr && !h->need_ranges && !h->cfg.ssim_opt && h->kc.qmode != 3 && h->num_cus > 0 && shared_one_launch_enabled()) {
+        if (!target || !params_ok(p) || !lists || !s || !params_ok(&s->m) || !params_ok(&s->v))
+            return fail(SMOE_ERR_INVALID, "smoe_shared_fit: target, params, adam state and lists are required");
+        HIP_TRY(hipSetDevice(h->cfg.device), "hipSetDevice");
+        smoe::SharedFitArgs f;
+        fill_shared_args(h, f.pass);
+        f.pass.target = target; f.pass.p = *p; f.pass.lists = lists; f.pass.b0 = 0; f.pass.NB = h->NB;
+        f.pass.loss = loss_last; f.pass.sse = sse_last; f.pass.recon = nullptr; f.pass.argmax = nullptr; f.pass.update_lists = 1;
+        fill_adam_args(h, p, s, f.adam);
+        f.n_iters = n_iters;
+        f.bar = h->d_bar;
+#if !SMOE_HOST_TEST
+        hipError_t e = hipMemsetAsync(h->d_bar, 0, sizeof(uint32_t) * h->bar_words, (hipStream_t)stream);
+        if (e == hipSuccess) e = smoe::launch_shared_fit(f, h->cfg.dim, h->cfg.channels, h->num_cus, (hipStream_t)stream);
+        if (e == hipSuccess) {
+            for (int i = 0; i < n_iters; ++i) {
+                s->beta1_power *= h->cfg.beta1;
+                s->beta2_power *= h->cfg.beta2;
+                h->epoch += 1u;
+                if (h->epoch == 0u) h->epoch = 1u;
+            }
+            s->step += n_iters;
+            h->fit_pending = true;
+#if defined(SMOE_PHASE_CLOCKS) && SMOE_PHASE_CLOCKS
+            {   // diagnostic build: ticks per iteration of the four phases, workgroup 0
+                uint32_t w[16];
+                if (hipMemcpy(w, h->d_bar, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess)
+                    std::fprintf(stderr, "shared_fit_kernel ticks/iteration: pass %.0f  barrier %.0f  gather+step %.0f  barrier %.0f\n",
+                                 w[8] / (double)n_iters, w[9] / (double)n_iters, w[10] / (double)n_iters, w[11] / (double)n_iters);
+            }
+#endif
+            return SMOE_OK;
+        }
+        (void)hipGetLastError();          // too many batches for one resident grid (or no cooperative launch): the loop below
+#endif
+    }
     for (int i = 0; i < n_iters; ++i) {
         int rc = shared_accumulate_impl(h, 0, h->NB, target, p, loss_last, sse_last, lists, stream, false);
         if (rc) return rc;

@@ -225,12 +225,26 @@ struct SharedRangesArgs {
     const float* mus_grid;    // as in SharedArgs
 };
 
+// smoe_shared_fit as one launch (shared_fit_kernel): the pass and step arguments of the first iteration (the kernel advances the
+// pass number and the beta powers itself), the iteration count, and the device words of the grid barrier, zeroed by the host
+// before the launch: bar[2] abort, bar[8 .. 11] phase clocks of the diagnostic build, bar[16 + w] arrival flag of workgroup w
+// (16 + NB rounded up to a multiple of four words)
+struct SharedFitArgs {
+    SharedArgs pass;
+    SharedAdamArgs adam;
+    int n_iters;
+    uint32_t* bar;
+};
+
 size_t shared_lds_bytes(int D, int C, int K, int KW);
 size_t shared_ssim_lds_bytes(int C, int Nb, int bh, int bw, int bt);
 bool shared_supported(int D, int C, int Nb);
 hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hipStream_t st);
 hipError_t launch_shared_adam(const SharedAdamArgs& a, int D, int C, hipStream_t st);
 hipError_t launch_shared_gather(const SharedGatherArgs& g, hipStream_t st);
+// hipErrorCooperativeLaunchTooLarge: the batches do not all fit on the device at once (the caller keeps its two launches per
+// iteration); num_cus = compute units of the device
+hipError_t launch_shared_fit(const SharedFitArgs& f, int D, int C, int num_cus, hipStream_t st);
 hipError_t launch_shared_readmit(const SharedReadmitArgs& a, int D, hipStream_t st);
 hipError_t launch_shared_ranges(const SharedRangesArgs& a, int D, int C, hipStream_t st);
 

@@ -75,6 +75,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Global accesses of the one-launch fit (shared_fit_kernel) that carry data BETWEEN workgroups inside the launch: the gfx950 L2
+// caches of the eight XCDs are not coherent with each other, so these loads / stores are device-scope relaxed atomics (sc1: the
+// store writes through, the load does not take a stale line) and the grid barrier needs no L2 write-back / invalidate -- 256
+// workgroups each running `buffer_wbl2` per barrier cost ~45 us per barrier.  COH = false: plain accesses (every other kernel).
+template <bool COH, class T>
+__device__ __forceinline__ T gload(const T* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH, class T>
+__device__ __forceinline__ void gstore(T* p, T v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // Fixed-range fake quant of the variables inside the graph (quantize_pis; quantization_mode 2; smoe.py:474-496):
 // group g: 0 A, 1 musX, 2 nu_e, 3 pis, 4 gamma_e.
 __device__ __forceinline__ bool fq_on(const KernelConsts& kc, int g) { return (g == 3) ? (kc.qpis != 0) : (kc.qmode == 2); }
@@ -101,15 +116,15 @@ __device__ __forceinline__ float fqt(float x, const KernelConsts& kc, const floa
 }
 // Centre l of kernel k as the graph reads it.  use_diff_center with quantization_mode 2 / 3 (G = the kernel-grid centres
 // [K][D], smoe.py:390-394,746-747): the quantised variable is the OFFSET musX - grid, the graph reads fq(offset) + grid.
-template <int D>
+template <int D, bool COH = false>
 __device__ __forceinline__ float mu_off(const float* __restrict__ musX, const float* __restrict__ G, const KernelConsts& kc, int k, int l) {
-    const float x = musX[(size_t)k * D + l];
+    const float x = gload<COH>(&musX[(size_t)k * D + l]);
     return (G != nullptr && kc.qmode >= 2) ? x - G[(size_t)k * D + l] : x;
 }
-template <int D>
+template <int D, bool COH = false>
 __device__ __forceinline__ float mu_graph(const float* __restrict__ musX, const float* __restrict__ G, const KernelConsts& kc,
                                           const float* rng, int k, int l) {
-    const float q = fqt(mu_off<D>(musX, G, kc, k, l), kc, rng, 2);
+    const float q = fqt(mu_off<D, COH>(musX, G, kc, k, l), kc, rng, 2);
     return (G != nullptr && kc.qmode >= 2) ? q + G[(size_t)k * D + l] : q;
 }
 // pis_l1 normaliser (smoe.py:1022-1027): start_pis, or the image-wide count of kernels with qpis > 0
@@ -127,14 +142,14 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 // the target of the batch go to LDS planes, the whole workgroup runs the SSIM stage of smoe_ssim.hip.h and reads dL/dq
 // back for the reverse sweep.
 // IC: train_inverse_cov (compile-time, it sits in the per-pixel gate).
-template <int D, int C, int PXL, bool TRAIN, bool SSIM = false, bool IC = false>
-__global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
+// (the body of the pass: one call per batch and workgroup -- by shared_pass_kernel once, by shared_fit_kernel once per iteration)
+template <int D, int C, int PXL, bool TRAIN, bool SSIM = false, bool IC = false, bool COH = false>
+__device__ __forceinline__ void shared_pass_body(const SharedArgs& a, const int b, float* __restrict__ lds) {
     using L = SL<D, C>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.x;                 // batch index inside this launch (buffers are launch-local)
+    // b: batch index inside this launch (buffers are launch-local)
     const int Nb = a.Nb;
     const int K = a.K;
 
@@ -158,12 +173,16 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     for (int kbase = 0; kbase < K; kbase += SH_THREADS) {
         const int k = kbase + tid;
         bool keep = false;
-        if (k < K && ((bits[k >> 5] >> (k & 31)) & 1u)) keep = fqv(a.p.pis[k], a.kc, 3) > 0.0f;
+        // (the list word and the prior are loaded together: the prior behind the bit test was a second memory round trip)
+        const int kc_ = (k < K) ? k : K - 1;
+        const uint32_t word = gload<COH>(&bits[kc_ >> 5]);
+        const float prior = gload<COH>(&a.p.pis[kc_]);
+        if (k < K && ((word >> (k & 31)) & 1u)) keep = fqv(prior, a.kc, 3) > 0.0f;
         const unsigned long long m = __ballot(keep);
         if (TRAIN && a.trained != nullptr && lane == 0) {                   // the kernels this pass trains here (gather step)
             const int w0 = (kbase + wave * 64) >> 5;
-            if (w0 < a.KW) a.trained[(size_t)(a.b0 + b) * a.KW + w0] = (uint32_t)m;
-            if (w0 + 1 < a.KW) a.trained[(size_t)(a.b0 + b) * a.KW + w0 + 1] = (uint32_t)(m >> 32);
+            if (w0 < a.KW) gstore<COH>(&a.trained[(size_t)(a.b0 + b) * a.KW + w0], (uint32_t)m);
+            if (w0 + 1 < a.KW) gstore<COH>(&a.trained[(size_t)(a.b0 + b) * a.KW + w0 + 1], (uint32_t)(m >> 32));
         }
         if (lane == 0) s_cnt[1 + wave] = __popcll(m);
         __syncthreads();
@@ -176,7 +195,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
     }
     const int Kact = s_cnt[0];
     for (int i = tid; i < Kact; i += SH_THREADS) s_flag[i] = 0;
-    if (TRAIN && a.batch_epoch != nullptr && tid == 0) a.batch_epoch[a.b0 + b] = a.epoch;
+    if (TRAIN && a.batch_epoch != nullptr && tid == 0) gstore<COH>(&a.batch_epoch[a.b0 + b], a.epoch);
 
     // ---- 1. this lane's pixels: global coordinates (smoe.py:2412) and targets --------------------
     int bo[D];                       // batch origin per axis (sliding_window order: last axis fastest)
@@ -222,7 +241,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int l = 0; l < D; ++l)
 #pragma unroll
                 for (int m = 0; m <= l; ++m) {
-                    A[l][m] = fqt((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, a.qrng, (l == m) ? 0 : 1);
+                    A[l][m] = fqt((l == m) ? gload<COH>(&a.p.A_diagonal[((size_t)k * D + l) * D + m]) : gload<COH>(&a.p.A_corr[((size_t)k * D + l) * D + m]), a.kc, a.qrng, (l == m) ? 0 : 1);
                     if (l == m) det *= A[l][m];
                     // train_inverse_cov: the coefficients c_lm of r^T A' r over l >= m, A' = SQ^2 A (smoe.py:734-735,791-793)
                     r[L::O_AS + tri(l, m)] = ic ? ((l == m) ? SQ * SQ : 2.0f * SQ * SQ) * A[l][m] : SQ * A[l][m];
@@ -231,20 +250,20 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             for (int m = 0; m < D; ++m) {
                 float cz = 0.0f;
                 if (ic) {
-                    cz = mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, m);   // the centre itself: r = x - mu per pixel
+                    cz = mu_graph<D, COH>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, m);   // the centre itself: r = x - mu per pixel
                 } else {
 #pragma unroll
-                    for (int l = m; l < D; ++l) cz = fmaf(mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l), SQ * A[l][m], cz);
+                    for (int l = m; l < D; ++l) cz = fmaf(mu_graph<D, COH>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l), SQ * A[l][m], cz);
                 }
                 r[L::O_CZ + m] = cz;
             }
             const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
-            r[L::O_COEF] = nq * fqv(a.p.pis[k], a.kc, 3);
+            r[L::O_COEF] = nq * fqv(gload<COH>(&a.p.pis[k]), a.kc, 3);
 #pragma unroll
-            for (int c = 0; c < C; ++c) r[L::O_NU + c] = fqt(a.p.nu_e[(size_t)k * C + c], a.kc, a.qrng, 3);
+            for (int c = 0; c < C; ++c) r[L::O_NU + c] = fqt(gload<COH>(&a.p.nu_e[(size_t)k * C + c]), a.kc, a.qrng, 3);
 #pragma unroll
             for (int i = 0; i < D * C; ++i)
-                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? fqt(a.p.gamma_e[(size_t)k * D * C + i], a.kc, a.qrng, 4) : 0.0f;
+                r[L::O_GA + i] = (a.kc.train_gammas && !(a.kc.only_y_gamma && (i % C) != 0)) ? fqt(gload<COH>(&a.p.gamma_e[(size_t)k * D * C + i]), a.kc, a.qrng, 4) : 0.0f;
         }
         __syncthreads();
     };
@@ -338,10 +357,10 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
         float Aq[D][D], rr[D];
 #pragma unroll
         for (int l = 0; l < D; ++l) {
-            rr[l] = xh[l] - mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
+            rr[l] = xh[l] - mu_graph<D, COH>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
 #pragma unroll
             for (int m = 0; m <= l; ++m) {
-                Aq[l][m] = fqt((l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : a.p.A_corr[((size_t)k * D + l) * D + m], a.kc, a.qrng, (l == m) ? 0 : 1);
+                Aq[l][m] = fqt((l == m) ? gload<COH>(&a.p.A_diagonal[((size_t)k * D + l) * D + m]) : gload<COH>(&a.p.A_corr[((size_t)k * D + l) * D + m]), a.kc, a.qrng, (l == m) ? 0 : 1);
                 if (l == m) det *= Aq[l][m];
             }
         }
@@ -387,7 +406,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                 float maha = 0.0f, det = 1.0f;
                 halo_maha(k, xh, maha, det);
                 const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
-                Sh += nq * fqv(a.p.pis[k], a.kc, 3) * fexp2(-maha);
+                Sh += nq * fqv(gload<COH>(&a.p.pis[k]), a.kc, 3) * fexp2(-maha);
             }
             const float invh = frcp(fmaxf(Sh, 10e-12f));
             for (int i = 0; i < Kact; ++i) {
@@ -395,7 +414,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                 float maha = 0.0f, det = 1.0f;
                 halo_maha(k, xh, maha, det);
                 const float nq = a.kc.use_det ? det / a.kc.n_dis : 1.0f;
-                if (nq * fqv(a.p.pis[k], a.kc, 3) * fexp2(-maha) * invh > a.kc.tau) s_flag[i] = 1;
+                if (nq * fqv(gload<COH>(&a.p.pis[k]), a.kc, 3) * fexp2(-maha) * invh > a.kc.tau) s_flag[i] = 1;
             }
         }
         __syncthreads();
@@ -532,7 +551,7 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
                 const float v = (s_acc[i] + s_acc[SH_KC * L::PK + i]) + (s_acc[2 * SH_KC * L::PK + i] + s_acc[3 * SH_KC * L::PK + i]);
                 // the batch's own row of the partial buffer (summed per kernel in batch order by the gather step: fixed order,
                 // bit-deterministic); without the buffer: fp64 atomics, whose order varies from run to run
-                if (a.part != nullptr) a.part[((size_t)(a.b0 + b) * K + s_list[c0 + kk]) * L::PK + j] = v;
+                if (a.part != nullptr) gstore<COH>(&a.part[((size_t)(a.b0 + b) * K + s_list[c0 + kk]) * L::PK + j], v);
                 else atomicAdd(&a.racc[(size_t)s_list[c0 + kk] * L::PK + j], (double)v);
             }
             if (a.part == nullptr && a.nact != nullptr)
@@ -557,8 +576,8 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             const float rp = reg_pi_of(a.reg_pi, a.kc, a.qrng);
             for (int i = 0; i < Kact; ++i) {
                 const int k = s_list[i];
-                lossv += rp * fqv(a.p.pis[k], a.kc, 3);
-                for (int l = 0; l < D; ++l) lossv += a.reg_u * fqt(a.p.A_diagonal[((size_t)k * D + l) * D + l], a.kc, a.qrng, 0);
+                lossv += rp * fqv(gload<COH>(&a.p.pis[k]), a.kc, 3);
+                for (int l = 0; l < D; ++l) lossv += a.reg_u * fqt(gload<COH>(&a.p.A_diagonal[((size_t)k * D + l) * D + l]), a.kc, a.qrng, 0);
             }
         }
         if (a.loss != nullptr) a.loss[b] = lossv;
@@ -573,24 +592,19 @@ __global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
             if (pv[p]) a.argmax[(size_t)b * Nb + p * SH_THREADS + tid] = (arg[p] >= 0) ? arg[p] : first;
     }
     if (a.update_lists)                                               // smoe.py:1763-1766
-        for (int i = tid; i < a.KW; i += SH_THREADS) a.lists[(size_t)b * a.KW + i] = s_bits[i];
+        for (int i = tid; i < a.KW; i += SH_THREADS) gstore<COH>(&a.lists[(size_t)b * a.KW + i], s_bits[i]);
+}
+
+template <int D, int C, int PXL, bool TRAIN, bool SSIM = false, bool IC = false>
+__global__ void __launch_bounds__(SH_THREADS) shared_pass_kernel(SharedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    shared_pass_body<D, C, PXL, TRAIN, SSIM, IC>(a, (int)blockIdx.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
 // one Adam step on the accumulated gradients (train_op, smoe.py:1788,1173-1193); clears the
 // accumulators for the next pass (zero_op, smoe.py:1613)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void adam_apply(float* var, float* m, float* v, float g, float lr, const SharedAdamArgs& a) {
-    if (lr == 0.0f) return;
-    if (a.clip > 0.0f) g = fminf(fmaxf(g, -a.clip), a.clip);
-    const float alpha = lr * sqrtf(1.0f - a.b2p) / (1.0f - a.b1p);
-    const float m2 = *m + (g - *m) * (1.0f - a.beta1);
-    const float v2 = *v + (g * g - *v) * (1.0f - a.beta2);
-    *m = m2;
-    *v = v2;
-    *var = *var - (m2 * alpha) / (sqrtf(v2) + a.eps);
-}
-
 // Everything one kernel contributes to the step: its variables raw and as the graph sees them, and the gradients
 // w.r.t. the (fake-quantised) graph variables incl. the l1 terms, before the backward of the fake-quant ops.
 template <int D, int C>
@@ -601,7 +615,7 @@ struct KernelStep {
 
 // Sum of the batches' rows of kernel k over the current pass, by the 64 lanes of a wavefront: lane l takes the batches
 // l, l + 64, ... in ascending order (fp64), then a butterfly over the lanes -- a fixed order.  Every lane returns the totals.
-template <int PK>
+template <int PK, bool COH = false>
 __device__ __forceinline__ void gather_kernel_sums(const SharedGatherArgs& g, int k, int lane, double (&s)[PK], double& cnt) {
 #pragma unroll
     for (int j = 0; j < PK; ++j) s[j] = 0.0;
@@ -617,11 +631,11 @@ __device__ __forceinline__ void gather_kernel_sums(const SharedGatherArgs& g, in
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int b = min(b0 + 64 * u, g.NB_total - 1);
-            ep[u] = g.batch_epoch[b];
-            tw[u] = g.trained[(size_t)b * g.KW + w];
+            ep[u] = gload<COH>(&g.batch_epoch[b]);
+            tw[u] = gload<COH>(&g.trained[(size_t)b * g.KW + w]);
             const float* r = g.part + ((size_t)b * g.K + k) * PK;
 #pragma unroll
-            for (int j = 0; j < PK; ++j) row[u][j] = r[j];
+            for (int j = 0; j < PK; ++j) row[u][j] = gload<COH>(&r[j]);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -651,7 +665,7 @@ __global__ void __launch_bounds__(64) shared_gather_kernel(SharedGatherArgs g) {
     }
 }
 
-template <int D, int C>
+template <int D, int C, bool COH = false>
 __device__ __forceinline__ void kernel_step_from(const SharedAdamArgs& a, int k, const float (&r)[SL<D, C>::PK], float nact, KernelStep<D, C>& S);
 
 template <int D, int C>
@@ -663,28 +677,28 @@ __device__ __forceinline__ void kernel_step(const SharedAdamArgs& a, int k, bool
     for (int j = 0; j < L::PK; ++j) { r[j] = (float)rk[j]; if (clear) rk[j] = 0.0; }
     const float nact = a.nact ? (float)a.nact[k] : 0.0f;
     if (a.nact && clear) a.nact[k] = 0.0;
-    kernel_step_from<D, C>(a, k, r, nact, S);
+    kernel_step_from<D, C, false>(a, k, r, nact, S);
 }
 
-template <int D, int C>
+template <int D, int C, bool COH>
 __device__ __forceinline__ void kernel_step_from(const SharedAdamArgs& a, int k, const float (&r)[SL<D, C>::PK], float nact, KernelStep<D, C>& S) {
     using L = SL<D, C>;
-    S.pi_raw = a.p.pis[k];
+    S.pi_raw = gload<COH>(&a.p.pis[k]);
     S.pi = fqv(S.pi_raw, a.kc, 3);
 #pragma unroll
     for (int l = 0; l < D; ++l) {
-        S.mu_raw[l] = mu_off<D>(a.p.musX, a.mus_grid, a.kc, k, l);        // the quantised variable (use_diff_center: the offset)
-        S.mu[l] = mu_graph<D>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
+        S.mu_raw[l] = mu_off<D, COH>(a.p.musX, a.mus_grid, a.kc, k, l);        // the quantised variable (use_diff_center: the offset)
+        S.mu[l] = mu_graph<D, COH>(a.p.musX, a.mus_grid, a.kc, a.qrng, k, l);
 #pragma unroll
         for (int m = 0; m < D; ++m) {
-            S.Araw[l][m] = (l == m) ? a.p.A_diagonal[((size_t)k * D + l) * D + m] : ((l > m) ? a.p.A_corr[((size_t)k * D + l) * D + m] : 0.0f);
+            S.Araw[l][m] = (l == m) ? gload<COH>(&a.p.A_diagonal[((size_t)k * D + l) * D + m]) : ((l > m) ? gload<COH>(&a.p.A_corr[((size_t)k * D + l) * D + m]) : 0.0f);
             S.A[l][m] = (l >= m) ? fqt(S.Araw[l][m], a.kc, a.qrng, (l == m) ? 0 : 1) : 0.0f;
         }
     }
 #pragma unroll
-    for (int c = 0; c < C; ++c) S.nu_raw[c] = a.p.nu_e[(size_t)k * C + c];
+    for (int c = 0; c < C; ++c) S.nu_raw[c] = gload<COH>(&a.p.nu_e[(size_t)k * C + c]);
 #pragma unroll
-    for (int i = 0; i < D * C; ++i) S.ga_raw[i] = a.p.gamma_e[(size_t)k * D * C + i];
+    for (int i = 0; i < D * C; ++i) S.ga_raw[i] = gload<COH>(&a.p.gamma_e[(size_t)k * D * C + i]);
     const float su = r[L::R_SU];
     const bool ic = a.kc.inverse_cov != 0;        // train_inverse_cov: suz holds sum u r_l, sxz holds sum u r_l r_m
     float suz[D];
@@ -726,15 +740,21 @@ __device__ __forceinline__ void kernel_step_from(const SharedAdamArgs& a, int k,
 }
 
 // TF1 ApplyAdam on every variable of kernel k with the routed gradients in S (optimizer groups smoe.py:1102-1104)
-template <int D, int C>
+template <int D, int C, bool COH = false>
 __device__ __forceinline__ void kernel_apply(const SharedAdamArgs& a, int k, KernelStep<D, C>& S) {
-    if (a.train_pis) adam_apply(&a.p.pis[k], &a.m.pis[k], &a.v.pis[k], S.g_pi, a.lr_pis, a);
-    if (a.train_musx) {
+    // One table of the kernel's variables, then ALL loads (variable, m, v), then the updates, then the stores: the loads are
+    // independent and issued together -- as one adam_apply after the other every variable paid its own memory round trip
+    // (device-scope loads of the one-launch fit: ~2 us each, 9 - 25 of them in a row).
+    constexpr int TRI = D * (D + 1) / 2;
+    constexpr int NV = 1 + D + TRI + C + D * C;
+    float* var[NV]; float* pm[NV]; float* pv[NV];
+    float g[NV], lr[NV];
+    int n = 0;
+    var[n] = &a.p.pis[k]; pm[n] = &a.m.pis[k]; pv[n] = &a.v.pis[k]; g[n] = S.g_pi; lr[n] = a.train_pis ? a.lr_pis : 0.0f; ++n;
 #pragma unroll
-        for (int l = 0; l < D; ++l) {
-            const size_t o = (size_t)k * D + l;
-            adam_apply(&a.p.musX[o], &a.m.musX[o], &a.v.musX[o], S.g_mu[l], a.lr_expert, a);
-        }
+    for (int l = 0; l < D; ++l) {
+        const size_t o = (size_t)k * D + l;
+        var[n] = &a.p.musX[o]; pm[n] = &a.m.musX[o]; pv[n] = &a.v.musX[o]; g[n] = S.g_mu[l]; lr[n] = a.train_musx ? a.lr_expert : 0.0f; ++n;
     }
     if (a.kc.radial) {        // radial_as (smoe.py:714-719): one value per kernel -> its gradient is the trace; A_corr untrained
         float tr = 0.0f;
@@ -748,24 +768,35 @@ __device__ __forceinline__ void kernel_apply(const SharedAdamArgs& a, int k, Ker
 #pragma unroll
         for (int m = 0; m <= l; ++m) {
             const size_t o = ((size_t)k * D + l) * D + m;
-            if (l == m) {
-                adam_apply(&a.p.A_diagonal[o], &a.m.A_diagonal[o], &a.v.A_diagonal[o], S.g_A[l][m], a.lr_steer, a);
-            } else if (!a.kc.radial) {
-                adam_apply(&a.p.A_corr[o], &a.m.A_corr[o], &a.v.A_corr[o], S.g_A[l][m], a.lr_steer, a);
-            }
+            if (l == m) { var[n] = &a.p.A_diagonal[o]; pm[n] = &a.m.A_diagonal[o]; pv[n] = &a.v.A_diagonal[o]; lr[n] = a.lr_steer; }
+            else { var[n] = &a.p.A_corr[o]; pm[n] = &a.m.A_corr[o]; pv[n] = &a.v.A_corr[o]; lr[n] = a.kc.radial ? 0.0f : a.lr_steer; }
+            g[n] = S.g_A[l][m]; ++n;
         }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         const size_t o = (size_t)k * C + c;
-        adam_apply(&a.p.nu_e[o], &a.m.nu_e[o], &a.v.nu_e[o], S.g_nu[c], a.lr_expert, a);
+        var[n] = &a.p.nu_e[o]; pm[n] = &a.m.nu_e[o]; pv[n] = &a.v.nu_e[o]; g[n] = S.g_nu[c]; lr[n] = a.lr_expert; ++n;
     }
-    if (a.train_gammas) {
 #pragma unroll
-        for (int i = 0; i < D * C; ++i) {
-            const size_t o = (size_t)k * D * C + i;
-            if (a.only_y_gamma && (i % C) != 0) continue;
-            adam_apply(&a.p.gamma_e[o], &a.m.gamma_e[o], &a.v.gamma_e[o], S.g_ga[i], a.lr_expert, a);
-        }
+    for (int i = 0; i < D * C; ++i) {
+        const size_t o = (size_t)k * D * C + i;
+        var[n] = &a.p.gamma_e[o]; pm[n] = &a.m.gamma_e[o]; pv[n] = &a.v.gamma_e[o]; g[n] = S.g_ga[i];
+        lr[n] = (a.train_gammas && !(a.only_y_gamma && (i % C) != 0)) ? a.lr_expert : 0.0f; ++n;
+    }
+    float x0[NV], m0[NV], v0[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { x0[i] = gload<COH>(var[i]); m0[i] = gload<COH>(pm[i]); v0[i] = gload<COH>(pv[i]); }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lr[i] == 0.0f) continue;                       // untrained: variable and slots stay (adam_apply)
+        float gi = g[i];
+        if (a.clip > 0.0f) gi = fminf(fmaxf(gi, -a.clip), a.clip);
+        const float alpha = lr[i] * sqrtf(1.0f - a.b2p) / (1.0f - a.b1p);
+        const float m2 = m0[i] + (gi - m0[i]) * (1.0f - a.beta1);
+        const float v2 = v0[i] + (gi * gi - v0[i]) * (1.0f - a.beta2);
+        gstore<COH>(pm[i], m2);
+        gstore<COH>(pv[i], v2);
+        gstore<COH>(var[i], x0[i] - (m2 * alpha) / (sqrtf(v2) + a.eps));
     }
 }
 
@@ -773,20 +804,19 @@ __device__ __forceinline__ void kernel_apply(const SharedAdamArgs& a, int k, Ker
 // the nudged range), kernels are independent
 // One wavefront per kernel.  a.gather.part != null: the wavefront first sums the batches' rows of its kernel (fixed order);
 // lane 0 then takes the step.
-template <int D, int C>
-__global__ void __launch_bounds__(64) shared_adam_kernel(SharedAdamArgs a) {
+template <int D, int C, bool COH = false>
+__device__ __forceinline__ void shared_adam_body(const SharedAdamArgs& a, const int k, const int lane) {
     using L = SL<D, C>;
-    const int k = blockIdx.x, lane = threadIdx.x;
     KernelStep<D, C> S;
     if (a.gather.part != nullptr) {
         double s[L::PK], cnt;
-        gather_kernel_sums<L::PK>(a.gather, k, lane, s, cnt);
+        gather_kernel_sums<L::PK, COH>(a.gather, k, lane, s, cnt);
         if (lane != 0) return;
         float r[L::PK];
 #pragma unroll
         for (int j = 0; j < L::PK; ++j) { r[j] = (float)s[j]; a.racc[(size_t)k * L::PK + j] = 0.0; }
         if (a.nact) a.nact[k] = 0.0;
-        kernel_step_from<D, C>(a, k, r, (float)cnt, S);
+        kernel_step_from<D, C, COH>(a, k, r, (float)cnt, S);
     } else {
         if (lane != 0) return;
         kernel_step<D, C>(a, k, true, S);
@@ -802,7 +832,107 @@ __global__ void __launch_bounds__(64) shared_adam_kernel(SharedAdamArgs a) {
     for (int c = 0; c < C; ++c) S.g_nu[c] = fq_pass(S.nu_raw[c], a.kc, 2) ? S.g_nu[c] : 0.0f;
 #pragma unroll
     for (int i = 0; i < D * C; ++i) S.g_ga[i] = fq_pass(S.ga_raw[i], a.kc, 4) ? S.g_ga[i] : 0.0f;
-    kernel_apply<D, C>(a, k, S);
+    kernel_apply<D, C, COH>(a, k, S);
+}
+
+template <int D, int C>
+__global__ void __launch_bounds__(64) shared_adam_kernel(SharedAdamArgs a) {
+    shared_adam_body<D, C>(a, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the whole fit of smoe_shared_fit as ONE launch (single GPU): every batch keeps its workgroup for all n_iters iterations;
+// pass -> grid barrier -> gather + Adam step (one wavefront per kernel, spread over the workgroups) -> grid barrier.
+// The same device functions in the same order as the two launches per iteration it replaces: bit-identical results.  What one
+// workgroup writes for another (the batches' rows, the new parameters) goes through device-scope relaxed atomics (gload / gstore
+// <true>), so the barrier is an arrival counter and a generation word without any cache maintenance.  The grid
+// must be co-resident (the host checks the occupancy and launches cooperatively); the barrier's spin is bounded -- a workgroup
+// that waits longer than ~2 s raises the abort word, every workgroup leaves at its next barrier and the host reports the failure
+// instead of a hung device.
+// ---------------------------------------------------------------------------------------------
+// bar[2]: abort word; bar[16 + w]: arrival flag of workgroup w = the number of the last barrier it has reached.  A workgroup
+// arrives with ONE store of its own flag (no read-modify-write on a shared counter: 256 of those in a row were ~5 us) and its
+// first wavefront polls all flags, four per lane and load (16-byte device-scope loads), until every workgroup has reached
+// barrier `gen`.
+__device__ __forceinline__ bool grid_barrier(uint32_t* __restrict__ bar, const int nwg, const int b, const uint32_t gen) {
+    // every store of this thread has been written through (the data that crosses workgroups goes through gstore<true>: sc1)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&bar[16 + b], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        uint32_t polls = 0u;
+        for (;;) {
+            bool ok = true;
+            for (int i0 = 4 * lane; i0 < nwg; i0 += 256) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                u4 v;
+                const uint32_t* src = bar + 16 + i0;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+                ok = ok && ((int)(v.x - gen) >= 0) && (i0 + 1 >= nwg || (int)(v.y - gen) >= 0)
+                        && (i0 + 2 >= nwg || (int)(v.z - gen) >= 0) && (i0 + 3 >= nwg || (int)(v.w - gen) >= 0);
+            }
+            if (__ballot(!ok) == 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1u << 21) || ((polls & 255u) == 0u && __hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(&bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
+// SMOE_PHASE_CLOCKS (diagnostic build, scripts/phase_clocks_shared.py): thread 0 of workgroup 0 sums the s_memtime ticks of the
+// four phases of an iteration into bar[8 .. 11] (pass, barrier, gather + step, barrier)
+#ifndef SMOE_PHASE_CLOCKS
+#define SMOE_PHASE_CLOCKS 0
+#endif
+#if SMOE_PHASE_CLOCKS
+#define SMOE_SCLK(i) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); sclk[i] += (uint32_t)(_t - sclk_last); sclk_last = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SMOE_SCLK(i) do { } while (0)
+#endif
+
+template <int D, int C, int PXL, bool IC>
+__global__ void __launch_bounds__(SH_THREADS) shared_fit_kernel(SharedFitArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = (int)blockIdx.x, nwg = (int)gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t epoch = f.pass.epoch;
+    float b1p = f.adam.b1p, b2p = f.adam.b2p;
+    uint32_t gen = 0u;                       // barriers passed (the flags start at zero)
+#if SMOE_PHASE_CLOCKS
+    uint32_t sclk[4] = {0u, 0u, 0u, 0u};
+    unsigned long long sclk_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (int it = 0; it < f.n_iters; ++it) {
+        {
+            SharedArgs a = f.pass;
+            a.epoch = epoch;
+            shared_pass_body<D, C, PXL, true, false, IC, true>(a, b, lds);
+        }
+        SMOE_SCLK(0);
+        if (!grid_barrier(f.bar, nwg, b, ++gen)) return;
+        SMOE_SCLK(1);
+        {
+            SharedAdamArgs ad = f.adam;
+            ad.b1p = b1p; ad.b2p = b2p; ad.gather.epoch = epoch;
+            for (int k = wave * nwg + b; k < ad.K; k += (SH_THREADS / 64) * nwg) shared_adam_body<D, C, true>(ad, k, lane);
+        }
+        SMOE_SCLK(2);
+        if (!grid_barrier(f.bar, nwg, b, ++gen)) return;
+        SMOE_SCLK(3);
+        b1p *= f.adam.beta1;
+        b2p *= f.adam.beta2;
+        epoch += 1u;
+        if (epoch == 0u) epoch = 1u;
+    }
+#if SMOE_PHASE_CLOCKS
+    if (b == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) f.bar[8 + i] = sclk[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1049,6 +1179,40 @@ hipError_t launch_shared_pass(const SharedArgs& a, int D, int C, bool train, hip
     if (D == 2 && C == 3) return launch_pass_dc<2, 3>(a, train, st);
     if (D == 3 && C == 1) return launch_pass_dc<3, 1>(a, train, st);
     if (D == 3 && C == 3) return launch_pass_dc<3, 3>(a, train, st);
+    return hipErrorInvalidValue;
+}
+
+template <int D, int C, int PXL>
+static hipError_t launch_fit_t(const SharedFitArgs& f, int num_cus, hipStream_t st) {
+    const size_t shm = shared_lds_bytes(D, C, f.pass.K, f.pass.KW);
+    auto kern = (f.pass.kc.inverse_cov != 0) ? shared_fit_kernel<D, C, PXL, true> : shared_fit_kernel<D, C, PXL, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SH_THREADS, shm);
+    if (e != hipSuccess) return e;
+    if ((long)per_cu * num_cus < (long)f.pass.NB) return hipErrorCooperativeLaunchTooLarge;     // the barrier needs every batch resident
+    SharedFitArgs args = f;
+    void* argv[] = {&args};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3(f.pass.NB), dim3(SH_THREADS), argv, (unsigned int)shm, st);
+}
+
+template <int D, int C>
+static hipError_t launch_fit_dc(const SharedFitArgs& f, int num_cus, hipStream_t st) {
+    const int pxl = (f.pass.Nb + SH_THREADS - 1) / SH_THREADS;
+    if (pxl <= 1) return launch_fit_t<D, C, 1>(f, num_cus, st);
+    if (pxl <= 2) return launch_fit_t<D, C, 2>(f, num_cus, st);
+    if (pxl <= 4) return launch_fit_t<D, C, 4>(f, num_cus, st);
+    if (C == 1 && pxl <= 8) return launch_fit_t<D, 1, 8>(f, num_cus, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_shared_fit(const SharedFitArgs& f, int D, int C, int num_cus, hipStream_t st) {
+    if (f.pass.ssim || f.adam.kc.qmode == 3 || f.pass.part == nullptr) return hipErrorInvalidValue;
+    if (D == 2 && C == 1) return launch_fit_dc<2, 1>(f, num_cus, st);
+    if (D == 2 && C == 3) return launch_fit_dc<2, 3>(f, num_cus, st);
+    if (D == 3 && C == 1) return launch_fit_dc<3, 1>(f, num_cus, st);
+    if (D == 3 && C == 3) return launch_fit_dc<3, 3>(f, num_cus, st);
     return hipErrorInvalidValue;
 }
 

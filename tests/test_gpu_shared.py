@@ -234,6 +234,42 @@ def test_shared_gradient_accumulation_is_bit_deterministic():
     assert np.array_equal(runs[0][1], runs[1][1])
 
 
+@pytest.mark.parametrize("case", [((128, 128), (16, 16), 1, [6, 6], {}), ((64, 96), (16, 32), 3, [4, 6], {"train_inverse_cov": True}),
+                                  ((32, 32, 8), (16, 16, 4), 1, [3, 3, 2], {"overlap": 2})])
+def test_one_launch_fit_equals_the_two_launches_per_iteration(case, monkeypatch):
+    """smoe_shared_fit as ONE launch (shared_fit_kernel: pass -> grid barrier -> gather + Adam -> grid barrier, n_iters times on
+    a resident grid) against the loop of two launches per iteration it replaces (SMOE_SHARED_ONE_LAUNCH=0): the same device
+    functions in the same order, so parameters, Adam slots, kernel lists, losses and the beta powers are bit-identical; also
+    when the iterations are cut into several calls."""
+    shape, bshape, C, kpd, kw = case
+    img, p, cfg, coords, tgt, K, NB = _setup(shape, bshape, C, kpd, C == 3)
+    T = torch.from_numpy(blk.to_planar(tgt.reshape((NB,) + tuple(bshape) + (C,)))).cuda()
+    runs = []
+    for mode, chunks in (("0", (25,)), ("1", (25,)), ("1", (7, 1, 17))):
+        monkeypatch.setenv("SMOE_SHARED_ONE_LAUNCH", mode)
+        eng = _engine(shape, bshape, C, K, C == 3, quantize_pis=True, lr_steer=0.05, **kw)
+        dq = _dev(p)
+        st = eng.new_adam_state(dq)
+        lists = eng.new_lists()
+        eng.forward(T, dq, lists, want_recon=False)
+        loss = torch.zeros(NB, device="cuda")
+        for n in chunks:
+            eng.fit(T, dq, st, lists, n, loss_out=loss)
+        f = eng.forward(T, dq, lists.clone(), want_recon=False)
+        torch.cuda.synchronize()
+        runs.append(({k: v.cpu().numpy() for k, v in dq.items()}, {k: v.cpu().numpy() for k, v in st.m.items()},
+                     {k: v.cpu().numpy() for k, v in st.v.items()}, lists.cpu().numpy().copy(), loss.cpu().numpy(),
+                     (float(st.c.beta1_power), float(st.c.beta2_power), int(st.c.step)), f["loss"].cpu().numpy()))
+        eng.close()
+    ref = runs[0]
+    assert np.isfinite(ref[4]).all() and ref[5][2] == 25
+    for other in runs[1:]:
+        for a, b in zip(ref[:3], other[:3]):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(ref[3], other[3]) and np.array_equal(ref[4], other[4]) and ref[5] == other[5] and np.array_equal(ref[6], other[6])
+
+
 def test_shared_facade_on_gpu_matches_the_oracle_backed_facade():
     from fake_engine import OracleSharedEngine
     from steered_mixture_of_experts_amd.smoe import Adam, SharedSmoe
