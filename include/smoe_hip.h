@@ -295,7 +295,11 @@ int smoe_shared_discard(smoe_shared_handle h, void* stream);
 /* Device pointer + length (in doubles) of the gradient accumulation buffer. */
 int smoe_shared_grad_buffer(smoe_shared_handle h, double** dev_ptr, int64_t* count);
 
-/* n_iters x (accumulate over ALL batches; apply): the single-GPU loop body of Smoe.train. */
+/* n_iters x (accumulate over ALL batches; apply): the single-GPU loop body of Smoe.train.  Two launches per iteration.
+ * Environment SMOE_SHARED_ONE_LAUNCH=1: all n_iters iterations in ONE cooperative launch (grid barriers between the pass and
+ * the step; bit-identical results; used when every batch fits on the device at once, margin loss, quantization_mode != 3) --
+ * measured slower on MI355X, so it is opt-in.  If such a launch had to give up (a grid barrier timed
+ * out), the next smoe_shared_fit / smoe_shared_forward call of the handle returns SMOE_ERR_HIP. */
 int smoe_shared_fit(smoe_shared_handle h, const float* target, smoe_params* p, smoe_adam_state* s, int32_t n_iters,
                     float* loss_last, float* sse_last, uint32_t* lists, void* stream);
 

@@ -137,6 +137,11 @@ __device__ __forceinline__ float* pick(const smoe_params& s, int tensor) {
 #ifndef SMOE_NT_STORES
 #define SMOE_NT_STORES 1
 #endif
+// one block per wavefront, parameter-rich triples (K * C >= 24): the wave-uniform constants of the pixel loop in scalar registers
+// (32x32 / K = 8 / RGB bound to 256 VGPRs: 61 -> 30 parked dwords, 110.8 -> 113.6 Gpx-it/s)
+#ifndef SMOE_SGPR_CONSTS
+#define SMOE_SGPR_CONSTS 1
+#endif
 // Diagnostic build (make EXTRA=-DSMOE_PHASE_CLOCKS=1; scripts/phase_clocks.py): lane 0 of every wavefront of workgroup 0 sums the
 // shader-clock cycles it spends in each phase of the fit iteration and leaves them in loss_out[wave * 8 + phase] -- the
 // loss outputs of the first blocks are garbage in such a build.
@@ -1647,6 +1652,24 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
                 }
             }
             if (HL > 0) hoist_const<D, C, K, HL, IC>(R, xc);
+#if SMOE_SGPR_CONSTS
+            // one block per wavefront: what the pixel loop reads of the parameters besides the lane's hoisted constants is the
+            // same in every lane -- scalar registers for the parameter-rich triples (one scalar operand per VALU instruction)
+            if constexpr (G == 64 && !SSIM && !QUANT && !IC && HL >= 1 && K * C >= 24) {
+                auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    R.coef[k] = uni(R.coef[k]);
+#pragma unroll
+                    for (int l = 0; l < D - HL; ++l) {
+#pragma unroll
+                        for (int m = 0; m <= l; ++m) R.As[k][tri_index(l, m)] = uni(R.As[k][tri_index(l, m)]);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) R.P[k * Lt::PK + Lt::O_GA + l * C + c] = uni(R.P[k * Lt::PK + Lt::O_GA + l * C + c]);
+                    }
+                }
+            }
+#endif
             SMOE_CLK(0);
             if constexpr (SSIM) {
                 // the reference's SSIM branch does not use loss_weights (smoe.py:929-1010)

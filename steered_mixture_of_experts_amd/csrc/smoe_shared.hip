@@ -6,8 +6,9 @@
 // One 256-thread workgroup per batch, PXL pixels per lane held in registers.  The batch's active
 // kernels are compacted into an LDS list and staged (with derived quantities) through LDS in chunks;
 // three sweeps over the list per pass: (A) gate normaliser S, (B) masked gate / experts / blend /
-// influence flags, (C) reverse pass with per-kernel raw sums reduced across the wavefront and
-// added to fp64 global accumulators (order effects of the atomics stay below fp32 resolution).
+// influence flags, (C) reverse pass with per-kernel raw sums reduced across the wavefront and written
+// to the batch's own rows of a partial buffer; a gather step sums the rows per kernel in batch order
+// (fixed order, bit-deterministic; fp64 atomics only when the rows would not fit in memory).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -505,22 +505,27 @@ class Smoe:
             w = w * self._loss_w
         return w.contiguous()
 
-    def _assemble(self, out):
-        """Full-image reconstruction / argmax / gate arrays from one pass's device outputs (smoe.py:1719-1783)."""
+    def _assemble_one(self, out, name):
+        """One full-image product (reconstruction / argmax / gate) from a pass's device outputs (smoe.py:1719-1783)."""
         bs, d = self.batch_size_valued, self.dim_domain
-        recon = blk.from_planar(out["recon"].cpu().numpy(), bs)                       # (B,*bs,C)
-        recon = sdist.allgather_blocks(recon, self.num_blocks)
-        image = blk.blocks_to_image(recon, self.image.shape[:d], bs)
-        am = out["argmax"].cpu().numpy().astype(np.int64).reshape((self.B,) + bs)
-        am = am + (np.arange(self.lo, self.hi, dtype=np.int64) * self.kernels).reshape((-1,) + (1,) * d)
-        am = sdist.allgather_blocks(am, self.num_blocks)
-        argmax = blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
+        if name == "image":
+            recon = blk.from_planar(out["recon"].cpu().numpy(), bs)                   # (B,*bs,C)
+            recon = sdist.allgather_blocks(recon, self.num_blocks)
+            return blk.blocks_to_image(recon, self.image.shape[:d], bs)
+        if name == "argmax":
+            am = out["argmax"].cpu().numpy().astype(np.int64).reshape((self.B,) + bs)
+            am = am + (np.arange(self.lo, self.hi, dtype=np.int64) * self.kernels).reshape((-1,) + (1,) * d)
+            am = sdist.allgather_blocks(am, self.num_blocks)
+            return blk.blocks_to_image(am[..., None], self.image.shape[:d], bs)[..., 0]
         gate = out["gate_w"].cpu().numpy().reshape((self.B, self._kp) + bs)[:, :self.kernels]
-        return image, argmax, sdist.allgather_blocks(gate, self.num_blocks)            # gate: (B,K,*bs)
+        return sdist.allgather_blocks(gate, self.num_blocks)                          # gate: (B,K,*bs)
+
+    def _assemble(self, out):
+        return tuple(self._assemble_one(out, n) for n in ("image", "argmax", "gate"))
 
     def _stitch(self, out, quantised=False):
         """Keep the products of an update_reconstruction pass.  Single process: the device tensors are kept and the
-        host copy + stitching (tens of ms for large images) happens when an attribute / getter asks; several ranks:
+        host copy + stitching (tens of ms for large images) happens per product when an attribute / getter asks; several ranks:
         assembled right away, because the gather is a collective every rank takes part in."""
         slot = "_qimages" if quantised else "_images"
         if self.world_size == 1:
@@ -536,9 +541,10 @@ class Smoe:
         st = getattr(self, slot)
         if st is None:
             return None
-        if "pending" in st:
-            st = dict(zip(("image", "argmax", "gate"), self._assemble(st["pending"])))
-            setattr(self, slot, st)
+        if name not in st:                 # single process: each product is copied to the host and stitched when first asked for
+            st[name] = self._assemble_one(st["pending"], name)
+            if all(n in st for n in ("image", "argmax", "gate")):
+                del st["pending"]
         return st[name]
 
     reconstruction_image = property(lambda self: self._image_product("_images", "image"))
