@@ -32,7 +32,26 @@ namespace smoe {
 // ---------------------------------------------------------------------------
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-// A value that is the same in every lane of the wavefront -> scalar register.
+
+// Fair share of a SIMD for the wavefronts of a ONE-ROUND launch (FitArgs::prio_rotate, set by the host when every wavefront of
+// the launch is resident at once).  The instruction arbiter serves the oldest wavefront first: of the two or three wavefronts
+// that start a launch together on a SIMD the first runs at nearly the lone-wavefront rate and the last finishes ~50 % later,
+// and the launch lasts as long as its slowest wavefront (12 288 blocks of 16x16: three per SIMD, 0.915 ms per 100 iterations,
+// while every FURTHER 768 workgroups of a longer launch cost 0.75 ms).  Rotating the user priority (s_setprio beats age) by one
+// level per iteration, offset by the hardware wave slot, gives every wavefront the same share: 12 288 blocks 336 -> 368
+// Gpx-it/s, 8 192: 302 -> 329, 4 096 (32 lanes): 235 -> 257, 2 048 (64 lanes): 166 -> 176.  In a launch of several rounds the
+// unfairness is useful (early finishers make room for the next round: 16 384 blocks lose 2 % with the rotation): not used there.
+__device__ __forceinline__ uint32_t hw_wave_slot() {
+    return __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));          // HW_REG_HW_ID, WAVE_ID[3:0]: the wave slot on its SIMD
+}
+__device__ __forceinline__ void rotate_priority(int it, uint32_t slot) {
+    const uint32_t pr = ((uint32_t)it + slot) % 3u;
+    if (pr == 0u) __builtin_amdgcn_s_setprio(0);
+    else if (pr == 1u) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+}
+// (the slot is read from the hardware register every iteration: kept in a scalar register across the iteration loop it cost the
+// headline kernel, which sits at the scalar-register limit, two VALU instructions in its pixel loop: -1 %)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 constexpr int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -1626,6 +1645,10 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     unsigned long long clk_last = __builtin_amdgcn_s_memtime();
 #endif
     for (int it = 0; it < a.n_iters; ++it) {
+        // wavefront priority of the iteration's first part (parameter image, derived constants, pixel loop): the rotating level
+        // in a one-round launch (rotate_priority), the lowest otherwise; the second part runs at the highest (below)
+        if (a.prio_rotate) rotate_priority(it, hw_wave_slot());
+        else if (G < 64) __builtin_amdgcn_s_setprio(0);
         float acc[Lt::NSLOT];
 #pragma unroll
         for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
@@ -1725,6 +1748,11 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
             if (HL > 0) complete_const<D, C, K, HL, IC>(R, xc, acc);
             SMOE_CLK(1);
         }
+        // The reduction and owner phases are chains of LDS round trips with few instructions; the other wavefronts of the SIMD are
+        // mostly in their pixel loops and issue continuously.  Served FIRST (s_setprio 3 until the next iteration starts) the
+        // chain is not held up behind them: 65 536 blocks 396 -> 406 Gpx-it/s, 12 288: 369 -> 387, 4 096 (32 lanes): 255 -> 260.
+        // Not on the one-block-per-wavefront tiling: most of its iteration IS this part (2 048 blocks: -3 %).
+        if (G < 64) __builtin_amdgcn_s_setprio(3);
         if (!owner_post) {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
             R2.load(s_img);

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include "smoe_device.h"
@@ -32,6 +34,8 @@ struct smoe_context {
     int lw_is_sample;    // smoe_set_sampling: the loss_w of smoe_fit is a pixel sub-sample
     int simds;           // SIMDs of the device (4 per CU; 1 024 on MI355X): the batch-size thresholds of the tiling rules scale with it
     std::string variant_name;   // what smoe_fit_variant last returned (the team names are composed)
+    // resident wavefronts per CU of the fit kernels asked about so far: (variant, kind 0 plain / 1 pair / 2 duo, loss weights) -> count
+    std::vector<std::pair<std::tuple<const void*, int, int>, int>> occ_cache;
     smoe::KernelConsts kc;
     std::vector<float> h_coords;
 };
@@ -693,6 +697,30 @@ int smoe_fit(smoe_handle h, int32_t num_blocks, const float* target, const float
     const smoe::Variant* v16 = nullptr;
     const int team = team_waves(h, num_blocks, loss_w != nullptr, &v16);
     const smoe::Variant* vduo = duo_variant(h, num_blocks, loss_w != nullptr);
+    a.prio_rotate = 0;
+#if !SMOE_HOST_TEST
+    {
+        // one round = every wavefront of the launch resident at once: the wavefronts' priorities rotate (rotate_priority).
+        // Occupancy of the plain kernel of the tiling (the SSIM / quantised / inverse-covariance instantiations need at least
+        // as many registers: their launches are classed as one round a little too often, which costs at most 2 %)
+        long waves = 0, per_cu = 0;
+        const smoe::Variant* vo = vduo ? vduo : v;
+        const int kind = vduo ? 2 : (a.pair ? 1 : 0);
+        if (team <= 0) {
+            waves = (kind != 0) ? 2L * num_blocks : ((long)num_blocks * v->G + 63) / 64;
+            const auto key = std::make_tuple((const void*)vo, kind, (int)(loss_w != nullptr));
+            bool found = false;
+            for (const auto& e : h->occ_cache)
+                if (e.first == key) { per_cu = e.second; found = true; break; }
+            if (!found) {          // (an occupancy query per launch would cost the short launches of a small batch microseconds)
+                per_cu = vduo ? vduo->duo_waves_per_cu(h->N, loss_w != nullptr, hoist_level(h, vduo))
+                              : v->fit_waves_per_cu(h->N, loss_w != nullptr, hoist, a.pair != 0);
+                h->occ_cache.emplace_back(key, (int)per_cu);
+            }
+        }
+        if (per_cu > 0 && waves <= per_cu * (long)(h->simds / 4)) a.prio_rotate = 1;
+    }
+#endif
     if (vduo) HIP_TRY(vduo->fit_duo(a, hoist_level(h, vduo), (hipStream_t)stream), "smoe_fit (duo) launch");
     else if (team > 0) HIP_TRY(v16->fit_team(a, hoist_level(h, v16), team, (hipStream_t)stream), "smoe_fit (team) launch");
     else if (c.ssim_opt) HIP_TRY(v->fit_ssim(a, hoist, (hipStream_t)stream), "smoe_fit (ssim) launch");

@@ -61,6 +61,7 @@ struct FitArgs {
     int pair;                 // few blocks: one block per 2-wavefront workgroup (64-lane tiling, margin loss; fit_kernel PAIR)
     int lds_floats;           // dynamic LDS of the launch in floats (set by the launcher; read by the SMOE_DEBUG carve-up checks)
     uint32_t* dbg;            // SMOE_DEBUG build: device word that collects failed device-side checks (null otherwise)
+    int prio_rotate;          // the launch is ONE round (every wavefront resident at once): rotate the wavefronts' priorities (smoe_block.hip.h)
     int lw_is_sample;         // loss_w is a pixel sub-sample (smoe_set_sampling): weight-0 pixels are not fed, they do not vote in the kernel-list prune
     KernelConsts kc;
 };

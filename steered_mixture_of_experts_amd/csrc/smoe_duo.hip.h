@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(128) fit_duo_kernel(FitArgs a) {
 #endif
 
     for (int it = 0; it < a.n_iters; ++it) {
+        if (a.prio_rotate) rotate_priority(it, hw_wave_slot());      // one-round launches: smoe_block.hip.h, rotate_priority
         const float* par = s_par0 + cur * Lt::LP_STRIDE;
         float* parn = s_par0 + (cur ^ 1) * Lt::LP_STRIDE;
         const uint32_t pb = cur ? PB1 : 0u;
