@@ -1644,11 +1644,12 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
     float clk[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     unsigned long long clk_last = __builtin_amdgcn_s_memtime();
 #endif
+    const bool phase_prio = !PAIR && (G < 64 || N >= 8 * G);       // (a compile-time constant on the 16- and 32-lane tilings)
     for (int it = 0; it < a.n_iters; ++it) {
         // wavefront priority of the iteration's first part (parameter image, derived constants, pixel loop): the rotating level
         // in a one-round launch (rotate_priority), the lowest otherwise; the second part runs at the highest (below)
         if (a.prio_rotate) rotate_priority(it, hw_wave_slot());
-        else if (G < 64) __builtin_amdgcn_s_setprio(0);
+        else if (phase_prio) __builtin_amdgcn_s_setprio(0);
         float acc[Lt::NSLOT];
 #pragma unroll
         for (int j = 0; j < Lt::NSLOT; ++j) acc[j] = 0.0f;
@@ -1751,8 +1752,9 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         // The reduction and owner phases are chains of LDS round trips with few instructions; the other wavefronts of the SIMD are
         // mostly in their pixel loops and issue continuously.  Served FIRST (s_setprio 3 until the next iteration starts) the
         // chain is not held up behind them: 65 536 blocks 396 -> 406 Gpx-it/s, 12 288: 369 -> 387, 4 096 (32 lanes): 255 -> 260.
-        // Not on the one-block-per-wavefront tiling: most of its iteration IS this part (2 048 blocks: -3 %).
-        if (G < 64) __builtin_amdgcn_s_setprio(3);
+        // Only where the pixel loop is the larger part of the iteration (at least eight pixels per lane): a 16x16 block on one
+        // wavefront spends most of its iteration IN this part (2 048 blocks: -3 %).
+        if (phase_prio) __builtin_amdgcn_s_setprio(3);
         if (!owner_post) {
             BlockRegs<D, C, K> R2;                           // re-read mu, A, pi (not kept live over the pixel loop)
             R2.load(s_img);
