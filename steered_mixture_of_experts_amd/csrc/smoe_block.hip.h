@@ -1752,6 +1752,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu
         // The reduction and owner phases are chains of LDS round trips with few instructions; the other wavefronts of the SIMD are
         // mostly in their pixel loops and issue continuously.  Served FIRST (s_setprio 3 until the next iteration starts) the
         // chain is not held up behind them: 65 536 blocks 396 -> 406 Gpx-it/s, 12 288: 369 -> 387, 4 096 (32 lanes): 255 -> 260.
+        // (Two rotating levels per part, as in the duo kernel, for launches with two wavefronts per SIMD: 4 096 blocks -5 %, 8 192: -3 %.)
         // Only where the pixel loop is the larger part of the iteration (at least eight pixels per lane): a 16x16 block on one
         // wavefront spends most of its iteration IN this part (2 048 blocks: -3 %).
         if (phase_prio) __builtin_amdgcn_s_setprio(3);
