@@ -460,12 +460,15 @@ struct PixelOut {
 // FLAGS: the influence test (smoe.py:829: any w~ > 0 over the block's pixels) is kept as one wavefront-wide lane mask per
 // kernel, OR-ed on the scalar unit from the compare that feeds the mask anyway, instead of a VALU add per kernel-pixel;
 // the caller turns the masks into the S_CNT partials after its loop.
-template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false, bool IC = false, bool FLAGS = false>
+// RAWLOSS (the training loop without per-pixel loss weights): the margin loss is accumulated per channel as sum (|diff| - eps)^2
+// in lraw[c] -- one fused multiply-add per channel and pixel -- and weighted by the channel weight once after the loop.
+template <int D, int C, int K, bool TRAIN, int HL = 0, bool EXTG = false, bool IC = false, bool FLAGS = false, bool RAWLOSS = false>
 __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelConsts& kc,
                                       const float (&x)[D], const float (&t)[C], float lw,
                                       float* __restrict__ acc, PixelOut<D, C, K>& o,
                                       const float* __restrict__ gext = nullptr,
-                                      unsigned long long* __restrict__ flags = nullptr, bool fed = true) {
+                                      unsigned long long* __restrict__ flags = nullptr, bool fed = true,
+                                      float* __restrict__ lraw = nullptr) {
     // fed = false: the pixel was not drawn by the sub-sampled pass (smoe.py:1664-1667: the reference feeds the drawn pixels
     // only), so it takes no part in the influence test that prunes the kernel list (smoe.py:829,1763-1766); its loss weight 0
     // keeps it out of the loss and of every gradient
@@ -538,7 +541,8 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         const float ad = fabsf(diff) - kc.epsm;
         acc[Lt::S_SSE] = fmaf(diff, diff, acc[Lt::S_SSE]);
         const float cwl = kc.cw[c] * lw;
-        if (!EXTG) acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
+        if constexpr (RAWLOSS) lraw[c] = fmaf(ad, ad, lraw[c]);
+        else if (!EXTG) acc[Lt::S_LOSS] = fmaf(cwl, ad * ad, acc[Lt::S_LOSS]);
         if (TRAIN) {
             // 2 cwl sign(diff): |diff| is either 0 or >= 2^-30, so diff * 2^100 saturates the clamp to +-2 cwl (loss weights are
             // not negative); ad * (+-2 cwl) rounds like 2 cwl * (+-ad): one multiply less than sign first, weight second
@@ -1311,6 +1315,10 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
     for (int k = 0; k < K; ++k) flags[k] = 0ull;
     // full steps: uniform control flow, so the lane-mask votes stay on the scalar unit.  Unrolled by two by hand: the
     // votes are convergent operations, which keeps the compiler from unrolling a loop of run-time trip count itself.
+    constexpr bool RAWL = !HAS_LW;
+    float lraw[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) lraw[c] = 0.0f;
     auto step = [&](int i) {
         const int n = i * G + sub;
         float x[D], t[C];
@@ -1320,7 +1328,7 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
         for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
         const float lw = HAS_LW ? s_lw[n] : 1.0f;
         PixelOut<D, C, K> o;
-        pixel<D, C, K, true, HL, false, IC, true>(R, kc, x, t, lw, acc, o, nullptr, flags, !(HAS_LW && sample) || lw != 0.0f);
+        pixel<D, C, K, true, HL, false, IC, true, RAWL>(R, kc, x, t, lw, acc, o, nullptr, flags, !(HAS_LW && sample) || lw != 0.0f, lraw);
     };
     int i = 0;
     if (full > 0) { step(0); i = 1; }              // peeled: with -fno-signed-zeros the zero initialisation of acc[] folds away
@@ -1342,8 +1350,12 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
             for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
             const float lw = HAS_LW ? s_lw[n] : 1.0f;
             PixelOut<D, C, K> o;
-            pixel<D, C, K, true, HL, false, IC>(R, kc, x, t, lw, acc, o, nullptr, nullptr, !(HAS_LW && sample) || lw != 0.0f);
+            pixel<D, C, K, true, HL, false, IC, false, RAWL>(R, kc, x, t, lw, acc, o, nullptr, nullptr, !(HAS_LW && sample) || lw != 0.0f, lraw);
         }
+    }
+    if constexpr (RAWL) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[Layout<D, C, K>::S_LOSS] = fmaf(kc.cw[c], lraw[c], acc[Layout<D, C, K>::S_LOSS]);
     }
     const int lane = threadIdx.x & 63;
 #pragma unroll
