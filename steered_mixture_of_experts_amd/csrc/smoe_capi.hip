@@ -27,6 +27,7 @@ struct smoe_context {
     const float* mus_grid;   // use_diff_center: kernel-grid centres [B,K,D] of the blocks the calls pass (smoe_set_center_grid), or null
     mutable int big_g;   // lanes per block for blocks of more than 512 pixels (big_block_lanes; -1: not asked yet)
     int pair_occ;        // wavefronts per CU the 64-lane fit kernel reaches (-1: not asked yet)
+    mutable int duo_occ[2];   // wavefronts per CU of the duo kernel without / with loss weights (-2: not asked yet, -1: unknown)
     int force_pair;      // 0: by batch size, 1: one block per 2-wavefront workgroup (smoe_set_tiling 128), -1: never
     long long total_blocks;   // smoe_set_total_blocks: block count of the whole job the calls are shards of (0: each call's own)
     int force_team;      // 0: by batch size, 2 / 4 / 8: team tiling with that many wavefronts per workgroup, -1: never
@@ -304,14 +305,27 @@ int team_waves(const smoe_context* h, int num_blocks, bool has_lw, const smoe::V
 const smoe::Variant* duo_variant(const smoe_context* h, int num_blocks, bool has_lw) {
     if (h->force_duo < 0 || (h->force_g && h->force_duo == 0) || h->force_team > 0) return nullptr;
     if (h->cfg.ssim_opt || h->kc.qmode || h->kc.inverse_cov || h->kc.radial) return nullptr;
-    if (h->force_duo == 0 && (h->force_pair > 0 || h->N > SMOE_DUO_MAX_PIXELS ||
-                              choice_blocks(h, num_blocks) > (long)SMOE_DUO_MAX_BLOCKS * h->simds / 1024)) return nullptr;
+    const long cb = choice_blocks(h, num_blocks);
+    const long one_per_simd = (long)SMOE_DUO_MAX_BLOCKS * h->simds / 1024;
+    if (h->force_duo == 0 && (h->force_pair > 0 || h->N > SMOE_DUO_MAX_PIXELS || cb > one_per_simd * 3 / 2)) return nullptr;
     int n = 0;
     const smoe::Variant* v = smoe::variants(&n);
     for (int i = 0; i < n; ++i) {
         if (v[i].D != h->cfg.dim || v[i].C != h->cfg.channels || v[i].K != h->cfg.kernels || v[i].G != 64 || !v[i].fit_duo) continue;
         const size_t b = v[i].duo_lds_bytes(h->N, has_lw, hoist_level(h, &v[i]));
         if (b == (size_t)-1 || b > 160u * 1024u) return nullptr;
+        if (h->force_duo == 0 && cb > one_per_simd) {
+            // Up to one and a half blocks per SIMD -- three of the kernel's wavefronts on every SIMD, all resident at once -- it
+            // still beats one wavefront per block (1 536 blocks of 16x16: 151 vs 132 Gpx-it/s, 1 280: 131 vs 112; 1 792, which
+            // needs a second round: 113 vs 148): only if the kernel's registers and LDS allow three wavefronts per SIMD.
+#if SMOE_HOST_TEST
+            return nullptr;
+#else
+            int& occ = h->duo_occ[has_lw ? 1 : 0];
+            if (occ == -2) occ = v[i].duo_waves_per_cu(h->N, has_lw, hoist_level(h, &v[i]));
+            if (occ < 12) return nullptr;
+#endif
+        }
         return &v[i];
     }
     return nullptr;
@@ -436,6 +450,7 @@ int smoe_create(smoe_handle* out, const smoe_config* cfg) {
 #endif
     h->total_blocks = 0;
     h->pair_occ = -1;
+    h->duo_occ[0] = h->duo_occ[1] = -2;
     h->big_g = -1;
     h->mus_grid = nullptr;
     h->d_coords = nullptr;
@@ -603,6 +618,9 @@ int smoe_set_total_blocks(smoe_handle h, int64_t total_blocks) {
 
 const char* smoe_fit_variant(smoe_handle h, int32_t num_blocks) {
     if (!h) return "";
+#if !SMOE_HOST_TEST
+    (void)hipSetDevice(h->cfg.device);       // (the duo rule asks the device for the kernel's occupancy)
+#endif
     if (const smoe::Variant* vd = duo_variant(h, num_blocks, false)) {
         h->variant_name = std::string(vd->name);
         const size_t g = h->variant_name.find("_g64");
