@@ -468,7 +468,9 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
                                       float* __restrict__ acc, PixelOut<D, C, K>& o,
                                       const float* __restrict__ gext = nullptr,
                                       unsigned long long* __restrict__ flags = nullptr, bool fed = true,
-                                      float* __restrict__ lraw = nullptr) {
+                                      float* __restrict__ lraw = nullptr, unsigned long long fedm = ~0ull) {
+    // fedm (FLAGS): lane mask of `fed`, voted once per pixel by the caller -- `__ballot(infl && fed)` per kernel made the
+    // compiler materialise the conjunction on the VALU (a v_cndmask + v_cmp per kernel and pixel in the loss-weight loop)
     // fed = false: the pixel was not drawn by the sub-sampled pass (smoe.py:1664-1667: the reference feeds the drawn pixels
     // only), so it takes no part in the influence test that prunes the kernel list (smoe.py:829,1763-1766); its loss weight 0
     // keeps it out of the loss and of every gradient
@@ -517,7 +519,7 @@ __device__ __forceinline__ void pixel(const BlockRegs<D, C, K>& R, const KernelC
         w[k] = g[k] * inv;
         const bool infl = w[k] > kc.tau;
         o.wt[k] = infl ? w[k] : 0.0f;
-        if constexpr (FLAGS) flags[k] |= __ballot(infl && fed);
+        if constexpr (FLAGS) flags[k] |= __ballot(infl) & fedm;
         else acc[Lt::S_CNT + k] += fed ? o.wt[k] : 0.0f;
         // smoe.py:840-848: e = nu + gamma^T x ; y = sum_k wt e
 #pragma unroll
@@ -1307,6 +1309,7 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
     // full steps: uniform control flow, so the lane-mask votes stay on the scalar unit.  Unrolled by two by hand: the
     // votes are convergent operations, which keeps the compiler from unrolling a loop of run-time trip count itself.
     constexpr bool RAWL = !HAS_LW;
+    const unsigned long long not_sampled = sample ? 0ull : ~0ull;           // wave-uniform: all pixels are fed unless the weights are a sample
     float lraw[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) lraw[c] = 0.0f;
@@ -1319,7 +1322,10 @@ __device__ __forceinline__ void pixel_loop_train(const BlockRegs<D, C, K>& R, co
         for (int c = 0; c < C; ++c) t[c] = s_tgt[c * N + n];
         const float lw = HAS_LW ? s_lw[n] : 1.0f;
         PixelOut<D, C, K> o;
-        pixel<D, C, K, true, HL, false, IC, true, RAWL>(R, kc, x, t, lw, acc, o, nullptr, flags, !(HAS_LW && sample) || lw != 0.0f, lraw);
+        const bool fed = !(HAS_LW && sample) || lw != 0.0f;
+        unsigned long long fedm = ~0ull;
+        if constexpr (HAS_LW) fedm = __ballot(lw != 0.0f) | not_sampled;        // (the vote of the compare itself, no branch in the step)
+        pixel<D, C, K, true, HL, false, IC, true, RAWL>(R, kc, x, t, lw, acc, o, nullptr, flags, fed, lraw, fedm);
     };
     int i = 0;
     if (full > 0) { step(0); i = 1; }              // peeled: with -fno-signed-zeros the zero initialisation of acc[] folds away
