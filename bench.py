@@ -54,6 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--block-shape", type=int, nargs="+", default=[16, 16])
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--kernels-per-dim", type=int, nargs="+", default=[2, 2])
+    ap.add_argument("--loss-weights", action="store_true",
+                    help="every block carries per-pixel loss weights (as the blocks of an image that is not a multiple of the block "
+                         "do: the last eighth of every block gets weight 0); not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quantize-pis", action="store_true",
                     help="diagnostic: run the constructor default (pis not fake-quantised) instead of the CLI default")
@@ -321,8 +324,13 @@ def worker(args):
 
     # the launch with its arguments marshalled once (engine.prepare_fit): between the start event and the launch only the C
     # call itself runs on the host, so that an event pair recorded into an idle stream measures the kernel, not Python
-    fit_n = eng.prepare_fit(target, params, state, active, diverged=diverged, loss0=loss0) if hasattr(eng, "prepare_fit") else \
-        (lambda n: eng.fit(target, params, state, active, n, diverged=diverged, loss0=loss0))
+    loss_w = None
+    if args.loss_weights:
+        loss_w = torch.ones((B, N), dtype=torch.float32, device=dev)
+        loss_w[:, N - N // 8:] = 0.0
+    lwkw = {} if loss_w is None else {"loss_w": loss_w}
+    fit_n = eng.prepare_fit(target, params, state, active, diverged=diverged, loss0=loss0, **lwkw) if hasattr(eng, "prepare_fit") else \
+        (lambda n: eng.fit(target, params, state, active, n, diverged=diverged, loss0=loss0, **lwkw))
 
     def run_steps(k, events=None):
         done = 0
@@ -496,6 +504,7 @@ def worker(args):
             "config": {"workload": f"{workload}, K={K} kernels/block, {args.steps} Adam iterations, CLI-default hyper-parameters",
                        "total_blocks": B_total, "blocks_rank0": B, "block_shape": list(shape), "channels": C, "kernels": K,
                        "iters_per_launch": ipl, "clock_warm_iters": args.clock_warm_iters, "kernel_variant": variant,
+                       "loss_weights": bool(args.loss_weights),
                        "kernel_variant_per_rank": variants,
                        "tiling_chosen_for_blocks": tiling_blocks if tiling_blocks else "each rank's own count",
                        "reps": reps, "timed_region_s_total": round(float(np.sum(times)), 4),
